@@ -1,0 +1,142 @@
+/*
+ * pcf_hip.h -- C ABI of libpcf_hip.so, the MI355X (gfx950) implementation of the
+ * PointConvFormer hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no torch types.  Every entry point
+ * replaces one function of the reference's `pcf_cuda` torch extension (or one of its Python kNN
+ * helpers); the reference interface each one stands in for is cited as file:line relative to the
+ * reference root.  `ml-pointconvformer_amd/pcf_cuda/__init__.py` binds these through ctypes under
+ * the reference's own module and function names (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *   - All pointers are DEVICE pointers (HIP), fp32 / int64 / int32 / uint8 as stated, dense
+ *     row-major ("contiguous" in the reference's CHECK_CONTIGUOUS sense, pcf.h:14-24).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls only enqueue work;
+ *     they never synchronise the device or the host (the reference does, pconv_ops.cu:887-889).
+ *   - Return value: 0 on success, a negative PCF_E_* code otherwise; pcf_hip_last_error() gives
+ *     the message for the calling thread.  Nothing is launched when an error is returned.
+ *   - Flattened aggregate channel index is c*C_mid + m, c over the C_in gathered channels first and
+ *     then the C_add appended ones; head of gathered channel c is c % H (pcf_ops.cu:60-68,
+ *     pconv_ops.cu:88-101, layers.py:387-390).  Backward kernels are the exact adjoint of that
+ *     forward layout (the reference's CUDA backward is not).
+ *   - Neighbour indices outside [0, N) contribute nothing (forward) and receive nothing (backward);
+ *     the reference reads out of bounds there.
+ *   - Outputs are fully written by the call; no pre-zeroing by the caller is needed.
+ *   - Workspaces: ask the matching *_workspace_bytes(), pass a device buffer at least that large
+ *     (16-byte aligned).  Contents are scratch.
+ */
+#ifndef PCF_HIP_H
+#define PCF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCF_OK 0
+#define PCF_E_BADARG (-1)     /* bad shape / null pointer / misaligned workspace */
+#define PCF_E_UNSUPPORTED (-2)/* shape outside what the kernels cover (message says which) */
+#define PCF_E_LAUNCH (-3)     /* HIP reported an error at launch */
+
+/* Library identity: "pcf_hip <version> gfx950". */
+const char* pcf_hip_version(void);
+/* Message of the last error returned on this thread ("" if none). */
+const char* pcf_hip_last_error(void);
+
+/* ---- guided aggregate (PCF) ------------------------------------------------------------------
+ * replaces pcf_cuda.pcf_forward / pcf_backward        (pcf_cuda.cpp:10-11, pcf.h:38-66,
+ *                                                       pcf_ops.cu:27-71,87-141,143-202)
+ * x [B,N,Ci] f32, idx [B,Nout,K] i64, guid [B,Nout,K,H] f32, w [B,Nout,K,Cm] f32
+ * out [B,Nout,Ci*Cm]:  out[b,n,c*Cm+m] = sum_k x[b,idx[b,n,k],c] * guid[b,n,k,c%H] * w[b,n,k,m]
+ */
+int pcf_hip_pcf_forward(const float* x, const int64_t* idx, const float* guid, const float* w,
+                        float* out, int B, int N, int Nout, int K, int Ci, int Cm, int H, void* stream);
+/* grad_x [B,N,Ci] (scatter-add, float atomics), grad_guid [B,Nout,K,H], grad_w [B,Nout,K,Cm]. */
+int pcf_hip_pcf_backward(const float* grad_out, const float* x, const int64_t* idx, const float* guid,
+                         const float* w, float* grad_x, float* grad_guid, float* grad_w, int B, int N,
+                         int Nout, int K, int Ci, int Cm, int H, void* stream);
+
+/* ---- unguided aggregate with appended per-edge features (PConv) ------------------------------
+ * replaces pcf_cuda.pconv_forward / pconv_backward     (pcf_cuda.cpp:12,14, pcf.h:81-112,
+ *                                                       pconv_ops.cu:40-103,240-290,648-776)
+ * add [B,Nout,K,Ca] f32 (Ca may be 0; then `add`/`grad_add` may be NULL)
+ * out [B,Nout,(Ci+Ca)*Cm]: out[b,n,c*Cm+m] = sum_k cat(x[b,idx[b,n,k]], add[b,n,k])[c] * w[b,n,k,m]
+ */
+int pcf_hip_pconv_forward(const float* x, const int64_t* idx, const float* w, const float* add,
+                          float* out, int B, int N, int Nout, int K, int Ci, int Ca, int Cm, void* stream);
+int pcf_hip_pconv_backward(const float* grad_out, const float* x, const int64_t* idx, const float* w,
+                           const float* add, float* grad_x, float* grad_w, float* grad_add, int B, int N,
+                           int Nout, int K, int Ci, int Ca, int Cm, void* stream);
+
+/* ---- aggregate + linear ----------------------------------------------------------------------
+ * replaces pcf_cuda.pconv_linear_forward AND pcf_cuda.pconv_linear_cutlass_forward
+ *                                                      (pcf_cuda.cpp:13,18, pcf.h:131-138,243-250,
+ *                                                       pconv_ops.cu:129-225,691-736,969-1269)
+ * lin_w [Co,(Ci+Ca)*Cm], lin_b [Co];  out [B,Nout,Co] = pconv_out . lin_w^T + lin_b,
+ * pconv_out [B,Nout,(Ci+Ca)*Cm] is returned as well (the reference saves it for backward).
+ */
+int pcf_hip_pconv_linear_forward(const float* x, const int64_t* idx, const float* w, const float* add,
+                                 const float* lin_w, const float* lin_b, float* out, float* pconv_out,
+                                 int B, int N, int Nout, int K, int Ci, int Ca, int Cm, int Co, void* stream);
+
+/* replaces pcf_cuda.pconv_linear_backward              (pcf_cuda.cpp:15, pcf.h:162-170,
+ *                                                       pconv_ops.cu:293-388,797-845)
+ * grad_x via float atomics.  grad_lin_w [Co,(Ci+Ca)*Cm], grad_lin_b [Co]. */
+size_t pcf_hip_pconv_linear_backward_workspace_bytes(int B, int N, int Nout, int K, int Ci, int Ca, int Cm,
+                                                     int Co);
+int pcf_hip_pconv_linear_backward(const float* grad_out, const float* x, const int64_t* idx, const float* w,
+                                  const float* add, const float* lin_w, const float* pconv_out, float* grad_x,
+                                  float* grad_w, float* grad_add, float* grad_lin_w, float* grad_lin_b,
+                                  void* workspace, size_t workspace_bytes, int B, int N, int Nout, int K,
+                                  int Ci, int Ca, int Cm, int Co, void* stream);
+
+/* replaces pcf_cuda.pconv_linear_opt_backward          (pcf_cuda.cpp:16, pcf.h:213-224,
+ *                                                       pconv_ops.cu:391-619,863-948)
+ * inv_neighbors i32 [B,inv_len], inv_k u8 [B,inv_len], inv_idx i32 [B,inv_idx_len] with
+ * inv_idx_len >= N+1: the CSR transpose of idx as produced by pcf_hip_knn_inverse.  grad_x is
+ * a deterministic gather-reduce over that CSR for EVERY input row (no atomics).  The reference
+ * uses the CSR only for rows >= Nout and does not check it matches idx; neither does this. */
+size_t pcf_hip_pconv_linear_opt_backward_workspace_bytes(int B, int N, int Nout, int K, int Ci, int Ca,
+                                                         int Cm, int Co);
+int pcf_hip_pconv_linear_opt_backward(const float* grad_out, const float* x, const int32_t* inv_neighbors,
+                                      const uint8_t* inv_k, const int32_t* inv_idx, const int64_t* idx,
+                                      const float* w, const float* add, const float* lin_w,
+                                      const float* pconv_out, float* grad_x, float* grad_w, float* grad_add,
+                                      float* grad_lin_w, float* grad_lin_b, void* workspace,
+                                      size_t workspace_bytes, int B, int N, int Nout, int K, int Ci, int Ca,
+                                      int Cm, int Co, int inv_len, int inv_idx_len, void* stream);
+
+/* ---- CSR transpose of the neighbour table ----------------------------------------------------
+ * replaces pcf_cuda.compute_knn_inverse                (pcf_cuda.cpp:17, pcf.h:183-186,
+ *                                                       knn.cu:24-168)
+ * idx [B,Nq,K] i64 -> inv_neighbors i32 [B,Nq*K], inv_k u8 [B,Nq*K], inv_idx i32 [B,total_points+1].
+ * Entries of idx outside [0,total_points) are skipped (knn.cu:38,76); unused tail entries are 0.
+ * Buckets are ordered by (query, k) -- deterministic; the reference's order is atomics-order.
+ * K <= 255 (inv_k is a byte). */
+size_t pcf_hip_knn_inverse_workspace_bytes(int B, int Nq, int K, int total_points);
+int pcf_hip_knn_inverse(const int64_t* idx, int32_t* inv_neighbors, uint8_t* inv_k, int32_t* inv_idx,
+                        void* workspace, size_t workspace_bytes, int B, int Nq, int K, int total_points,
+                        void* stream);
+
+/* ---- k nearest neighbours over a packed batch ------------------------------------------------
+ * replaces knn_post_dataloader_utils.compute_knn / knn_keops, one call per (level, relation)
+ * instead of one per (sample, level, relation)         (knn_post_dataloader_utils.py:22-87,171-223)
+ * ref [Nr,3] f32, query [Nq,3] f32 packed over n_seg samples; ref_off / query_off i32 [n_seg+1]
+ * (device) are the per-sample prefix offsets.  out i64 [Nq,K]: for each query the K nearest refs
+ * OF ITS OWN SAMPLE as global (packed) ref indices, ordered by (distance, index) ascending, where
+ * distance = ((rx-qx)^2 + (ry-qy)^2) + (rz-qz)^2 in fp32, one rounding per operation.
+ * Samples with fewer than K refs get -1 in the unfilled slots.  K <= 64. */
+int pcf_hip_knn(const float* ref, const float* query, const int32_t* ref_off, const int32_t* query_off,
+                int n_seg, int max_queries_per_seg, int K, int64_t* out, void* stream);
+
+/* ---- dense fp32 contraction used by the linear stage (exposed for tests / roofline) ----------
+ * C[M,N] = A[M,Kd] . B^T  (+ bias[N] if bias != NULL), B given as [N,Kd] row-major.  MFMA f32. */
+int pcf_hip_gemm_nt(const float* A, const float* Bm, const float* bias, float* C, int M, int N, int Kd,
+                    void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCF_HIP_H */

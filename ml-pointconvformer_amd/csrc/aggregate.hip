@@ -1,0 +1,574 @@
+// Neighbourhood aggregate of PointConv / PointConvFormer, forward and backward, for gfx950.
+//
+//   out[n, c*Cm+m] = sum_k T[n,k,c] * w[n,k,m],   T[n,k,:] = [ x[idx[n,k], :] (*) guid[n,k, c%H] | add[n,k,:] ]
+//
+// One workgroup (4 waves) owns P consecutive output points.  The irregular part -- the K gathered
+// rows per point -- is read with 16-byte loads that are contiguous inside a row, staged once in
+// LDS next to the point's w / guid / grad_out tiles, and every contraction over K, C or Cm then
+// runs out of LDS with one wave per point.  HBM traffic is therefore the algorithmic minimum:
+// each index, weight, guidance value and output element is touched exactly once, gathered rows
+// once per edge (served mostly from L2 / Infinity Cache: neighbourhoods overlap).
+//
+// Replaces pcf_cuda_forward/backward_kernel (pcf_ops.cu:27-141) and pconv_cuda_forward/
+// backward_kernel (pconv_ops.cu:40-103,240-290).  Backward is the adjoint of the forward
+// layout.  grad_x is either float-atomic scatter-add (no CSR available) or a plain
+// store of every edge's contribution row for the CSR gather-reduce in csr_reduce_kernel.
+#include <algorithm>
+
+#include "pcf_common.h"
+
+namespace pcf {
+
+struct AggArgs {
+    // forward inputs
+    const float* x;        // [B*N, Ci]
+    const int64_t* idx;    // [total, K]
+    const float* guid;     // [total, K, H] or null
+    const float* w;        // [total, K, Cm]
+    const float* add;      // [total, K, Ca] or null
+    float* out;            // fwd: [total, CT*Cm]
+    // backward
+    const float* gout;     // [total, CT*Cm]
+    float* gx;             // [B*N, Ci]      atomic target (SCATTER_ATOMIC)
+    float* contrib;        // [total*K, Ci]  per-edge rows (SCATTER_STORE)
+    float* gguid;          // [total, K, H]
+    float* gw;             // [total, K, Cm]
+    float* gadd;           // [total, K, Ca]
+    int total, N, Nout, K, Ci, Ca, Cm, H;
+    int P;                 // points per workgroup
+    int TS;                // LDS row stride of the gathered tile (floats)
+    int GS;                // LDS row stride of the grad_out tile (floats)
+    int offG, offT, offD, offW, offO;   // LDS offsets in floats (index table sits at 0)
+};
+
+__device__ __forceinline__ int pow2_ceil_dev(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+// ---- phases shared by forward and backward -----------------------------------------------------
+// phase 0: neighbour table -> LDS as int32 row numbers into the flattened [B*N] input (-1 = skip),
+//          guidance tile -> LDS.
+__device__ __forceinline__ void stage_index_and_guidance(const AggArgs& a, int n0, int np, int* sIdx, float* sG) {
+    const int tid = threadIdx.x;
+    const int K = a.K;
+    for (int u = tid; u < np * K; u += BLOCK) {
+        const int n = n0 + u / K;
+        const int b = n / a.Nout;
+        const int64_t j = a.idx[(size_t)n0 * K + u];
+        sIdx[u] = (j >= 0 && j < a.N) ? (int)((int64_t)b * a.N + j) : -1;
+    }
+    if (a.guid) {
+        const int cnt = np * K * a.H;
+        const float* g = a.guid + (size_t)n0 * K * a.H;
+        for (int u = tid; u < cnt; u += BLOCK) sG[u] = g[u];
+    }
+}
+
+// phase 1: gathered rows (optionally head-modulated), appended features and weights -> LDS.
+template <bool VROW, bool MODULATE>
+__device__ __forceinline__ void stage_tiles(const AggArgs& a, int n0, int np, const int* sIdx, const float* sG,
+                                            float* sT, float* sW, int Cm) {
+    const int tid = threadIdx.x;
+    const int K = a.K, Ci = a.Ci, Ca = a.Ca, TS = a.TS, H = a.H;
+    const HeadMod hm(H > 0 ? H : 1);
+    if (VROW) {
+        const int ci4 = Ci >> 2;
+        const int cnt = np * K * ci4;
+#pragma unroll 4
+        for (int u = tid; u < cnt; u += BLOCK) {
+            const int pk = u / ci4;
+            const int c = (u - pk * ci4) << 2;
+            const int row = sIdx[pk];
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row >= 0) v = ld4(a.x + (size_t)row * Ci + c);
+            if (MODULATE && a.guid) {
+                const float* g = sG + pk * H;
+                v.x *= g[hm(c)];
+                v.y *= g[hm(c + 1)];
+                v.z *= g[hm(c + 2)];
+                v.w *= g[hm(c + 3)];
+            }
+            st4(sT + pk * TS + c, v);
+        }
+        if (Ca > 0) {
+            const int ca4 = Ca >> 2;
+            const int cnta = np * K * ca4;
+            const float* src = a.add + (size_t)n0 * K * Ca;
+#pragma unroll 2
+            for (int u = tid; u < cnta; u += BLOCK) {
+                const int pk = u / ca4;
+                const int c = (u - pk * ca4) << 2;
+                st4(sT + pk * TS + Ci + c, ld4(src + (size_t)u * 4));
+            }
+        }
+    } else {
+        const int cnt = np * K * Ci;
+        for (int u = tid; u < cnt; u += BLOCK) {
+            const int pk = u / Ci;
+            const int c = u - pk * Ci;
+            const int row = sIdx[pk];
+            float v = row >= 0 ? a.x[(size_t)row * Ci + c] : 0.f;
+            if (MODULATE && a.guid) v *= sG[pk * H + hm(c)];
+            sT[pk * TS + c] = v;
+        }
+        if (Ca > 0) {
+            const int cnta = np * K * Ca;
+            const float* src = a.add + (size_t)n0 * K * Ca;
+            for (int u = tid; u < cnta; u += BLOCK) {
+                const int pk = u / Ca;
+                sT[pk * TS + Ci + (u - pk * Ca)] = src[u];
+            }
+        }
+    }
+    // weights: a contiguous [np*K*Cm] run
+    {
+        const int cnt = np * K * Cm;
+        const float* src = a.w + (size_t)n0 * K * Cm;
+        if ((Cm & 3) == 0 && VROW) {
+#pragma unroll 2
+            for (int u = tid; u < (cnt >> 2); u += BLOCK) st4(sW + u * 4, ld4(src + (size_t)u * 4));
+        } else {
+            for (int u = tid; u < cnt; u += BLOCK) sW[u] = src[u];
+        }
+    }
+}
+
+// ---- forward ------------------------------------------------------------------------------------
+// CM > 0: compile-time Cm (multiple of 4 -> four m per lane, else one); CM == 0: run-time Cm.
+template <int CM, bool VROW>
+__global__ __launch_bounds__(BLOCK) void agg_fwd_kernel(const AggArgs a) {
+    extern __shared__ __align__(16) float smem[];
+    int* sIdx = reinterpret_cast<int*>(smem);
+    float* sG = smem + a.offG;
+    float* sT = smem + a.offT;
+    float* sW = smem + a.offW;
+    const int n0 = blockIdx.x * a.P;
+    const int np = min(a.P, a.total - n0);
+    const int K = a.K, CT = a.Ci + a.Ca, TS = a.TS;
+    const int Cm = CM ? CM : a.Cm;
+
+    stage_index_and_guidance(a, n0, np, sIdx, sG);
+    __syncthreads();
+    stage_tiles<VROW, true>(a, n0, np, sIdx, sG, sT, sW, Cm);
+    __syncthreads();
+
+    const int lane = lane_id();
+    for (int p = wave_id(); p < np; p += NWAVE) {
+        const float* tp = sT + p * K * TS;
+        const float* wp = sW + p * K * Cm;
+        float* op = a.out + (size_t)(n0 + p) * CT * Cm;
+        if (CM > 0 && (CM & 3) == 0) {
+            constexpr int MQ = CM > 0 ? (CM >> 2) : 1;
+            for (int it = lane; it < CT * MQ; it += WAVE) {
+                const int c = it / MQ;
+                const int mv = (it - c * MQ) << 2;
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+                for (int k = 0; k < K; ++k) acc = fma4(tp[k * TS + c], ld4(wp + k * Cm + mv), acc);
+                st4(op + (size_t)it * 4, acc);
+            }
+        } else {
+            for (int it = lane; it < CT * Cm; it += WAVE) {
+                const int c = it / Cm;
+                const int m = it - c * Cm;
+                float acc = 0.f;
+#pragma unroll 4
+                for (int k = 0; k < K; ++k) acc = fmaf(tp[k * TS + c], wp[k * Cm + m], acc);
+                op[it] = acc;
+            }
+        }
+    }
+}
+
+// ---- backward -----------------------------------------------------------------------------------
+template <int CM, bool VROW, bool SCATTER_ATOMIC>
+__global__ __launch_bounds__(BLOCK) void agg_bwd_kernel(const AggArgs a) {
+    extern __shared__ __align__(16) float smem[];
+    int* sIdx = reinterpret_cast<int*>(smem);
+    float* sG = smem + a.offG;
+    float* sT = smem + a.offT;   // raw gathered rows | add ; gathered part becomes x*guid in phase 2
+    float* sD = smem + a.offD;   // (dL/dT) * x_raw, reduced per head in phase 3 (guided only)
+    float* sW = smem + a.offW;
+    float* sO = smem + a.offO;   // grad_out tile, row stride GS
+    const int tid = threadIdx.x;
+    const int n0 = blockIdx.x * a.P;
+    const int np = min(a.P, a.total - n0);
+    const int K = a.K, Ci = a.Ci, Ca = a.Ca, CT = Ci + Ca, TS = a.TS, GS = a.GS, H = a.H;
+    const int Cm = CM ? CM : a.Cm;
+    const bool guided = a.guid != nullptr;
+    const HeadMod hm(H > 0 ? H : 1);
+
+    stage_index_and_guidance(a, n0, np, sIdx, sG);
+    __syncthreads();
+    stage_tiles<VROW, false>(a, n0, np, sIdx, sG, sT, sW, Cm);
+    {   // grad_out: contiguous [np*CT*Cm] run -> rows of stride GS
+        const float* src = a.gout + (size_t)n0 * CT * Cm;
+        if (CM > 0 && (CM & 3) == 0 && VROW) {
+            constexpr int MQ = CM > 0 ? (CM >> 2) : 1;
+            const int cnt = np * CT * MQ;
+#pragma unroll 2
+            for (int u = tid; u < cnt; u += BLOCK) {
+                const int r = u / MQ;
+                st4(sO + r * GS + ((u - r * MQ) << 2), ld4(src + (size_t)u * 4));
+            }
+        } else {
+            const int cnt = np * CT * Cm;
+            for (int u = tid; u < cnt; u += BLOCK) {
+                const int r = u / Cm;
+                sO[r * GS + (u - r * Cm)] = src[u];
+            }
+        }
+    }
+    __syncthreads();
+
+    const int lane = lane_id();
+    // phase 2: dT[k,c] = sum_m gout[c,m] * w[k,m];  scatter / store its gathered part, write its appended part.
+    {
+        const int stride_c = CT >= WAVE ? WAVE : pow2_ceil_dev(CT);
+        const int groups = WAVE / stride_c;
+        const int cl = lane & (stride_c - 1);
+        const int kg = lane / stride_c;
+        for (int p = wave_id(); p < np; p += NWAVE) {
+            const size_t n = (size_t)(n0 + p);
+            for (int c = cl; c < CT; c += stride_c) {
+                float go[CM > 0 ? CM : 1];
+                if (CM > 0) {
+                    if ((CM & 3) == 0) {
+#pragma unroll
+                        for (int q = 0; q < CM / 4; ++q) {
+                            const float4 v = ld4(sO + (p * CT + c) * GS + q * 4);
+                            go[q * 4 + 0] = v.x; go[q * 4 + 1] = v.y; go[q * 4 + 2] = v.z; go[q * 4 + 3] = v.w;
+                        }
+                    } else {
+#pragma unroll
+                        for (int m = 0; m < CM; ++m) go[m] = sO[(p * CT + c) * GS + m];
+                    }
+                }
+                for (int k = kg; k < K; k += groups) {
+                    const int pk = p * K + k;
+                    const float* wr = sW + pk * Cm;
+                    float dT = 0.f;
+                    if (CM > 0) {
+                        if ((CM & 3) == 0) {
+#pragma unroll
+                            for (int q = 0; q < CM / 4; ++q)
+                                dT = dot4(make_float4(go[q * 4], go[q * 4 + 1], go[q * 4 + 2], go[q * 4 + 3]),
+                                          ld4(wr + q * 4), dT);
+                        } else {
+#pragma unroll
+                            for (int m = 0; m < CM; ++m) dT = fmaf(go[m], wr[m], dT);
+                        }
+                    } else {
+                        const float* orow = sO + (p * CT + c) * GS;
+                        for (int m = 0; m < Cm; ++m) dT = fmaf(orow[m], wr[m], dT);
+                    }
+                    if (c < Ci) {
+                        float gh = 1.f;
+                        if (guided) {
+                            gh = sG[pk * H + hm(c)];
+                            const float xr = sT[pk * TS + c];
+                            sD[pk * TS + c] = dT * xr;
+                            sT[pk * TS + c] = xr * gh;
+                        }
+                        if (SCATTER_ATOMIC) {
+                            const int row = sIdx[pk];
+                            if (row >= 0) atomicAdd(a.gx + (size_t)row * Ci + c, dT * gh);
+                        } else {
+                            a.contrib[(n * K + k) * Ci + c] = dT * gh;
+                        }
+                    } else {
+                        a.gadd[(n * K + k) * Ca + (c - Ci)] = dT;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // phase 3: grad_w[k,m] = sum_c gout[c,m] * T[k,c];  grad_guid[k,h] = sum_{c%H==h} dT[k,c]*x[k,c]
+    for (int p = wave_id(); p < np; p += NWAVE) {
+        const size_t n = (size_t)(n0 + p);
+        const float* orow = sO + p * CT * GS;
+        if (CM > 0 && (CM & 3) == 0) {
+            constexpr int MQ = CM > 0 ? (CM >> 2) : 1;
+            for (int it = lane; it < K * MQ; it += WAVE) {
+                const int k = it / MQ;
+                const int mv = (it - k * MQ) << 2;
+                const float* tr = sT + (p * K + k) * TS;
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+                for (int c = 0; c < CT; ++c) acc = fma4(tr[c], ld4(orow + c * GS + mv), acc);
+                st4(a.gw + (n * K) * Cm + (size_t)it * 4, acc);
+            }
+        } else {
+            for (int it = lane; it < K * Cm; it += WAVE) {
+                const int k = it / Cm;
+                const int m = it - k * Cm;
+                const float* tr = sT + (p * K + k) * TS;
+                float acc = 0.f;
+#pragma unroll 4
+                for (int c = 0; c < CT; ++c) acc = fmaf(tr[c], orow[c * GS + m], acc);
+                a.gw[(n * K) * Cm + it] = acc;
+            }
+        }
+        if (guided) {
+            for (int it = lane; it < K * H; it += WAVE) {
+                const int k = it / H;
+                const int h = it - k * H;
+                const float* dr = sD + (p * K + k) * TS;
+                float acc = 0.f;
+                for (int c = h; c < Ci; c += H) acc += dr[c];
+                a.gguid[(n * K) * H + it] = acc;
+            }
+        }
+    }
+}
+
+// ---- CSR gather-reduce of the per-edge contribution rows -----------------------------------------
+// grad_x[r, :] = sum over the inverse list of input row r of contrib[(n*K + k), :], in list order
+// (deterministic).  One wave per input row; lane groups take alternate list entries.
+// Stands in for input_only_backward_kernel (pconv_ops.cu:539-619) but covers every row.
+__global__ __launch_bounds__(BLOCK) void csr_reduce_kernel(const float* __restrict__ contrib,
+                                                           const int32_t* __restrict__ inv_n,
+                                                           const uint8_t* __restrict__ inv_k,
+                                                           const int32_t* __restrict__ inv_idx, float* __restrict__ gx,
+                                                           int B, int N, int Nout, int K, int Ci, int inv_len,
+                                                           int inv_idx_len) {
+    const int lane = lane_id();
+    const int stride_c = Ci >= WAVE ? WAVE : pow2_ceil_dev(Ci);
+    const int groups = WAVE / stride_c;
+    const int cl = lane & (stride_c - 1);
+    const int eg = lane / stride_c;
+    const long long rows = (long long)B * N;
+    for (long long r = (long long)blockIdx.x * NWAVE + wave_id(); r < rows; r += (long long)gridDim.x * NWAVE) {
+        const int b = (int)(r / N);
+        const int p = (int)(r - (long long)b * N);
+        int beg = inv_idx[(size_t)b * inv_idx_len + p];
+        int end = inv_idx[(size_t)b * inv_idx_len + p + 1];
+        beg = max(0, min(beg, inv_len));
+        end = max(beg, min(end, inv_len));
+        const int32_t* ln = inv_n + (size_t)b * inv_len;
+        const uint8_t* lk = inv_k + (size_t)b * inv_len;
+        for (int c0 = 0; c0 < Ci; c0 += stride_c) {
+            const int c = c0 + cl;
+            float acc = 0.f;
+            if (c < Ci) {
+                for (int j = beg + eg; j < end; j += groups) {
+                    const int n = ln[j];
+                    const int k = lk[j];
+                    if (n >= 0 && n < Nout && k < K) acc += contrib[(((size_t)b * Nout + n) * K + k) * Ci + c];
+                }
+            }
+            for (int off = stride_c; off < WAVE; off <<= 1) acc += __shfl_xor(acc, off, WAVE);
+            if (eg == 0 && c < Ci) gx[(size_t)r * Ci + c] = acc;
+        }
+    }
+}
+
+// ---- host side ----------------------------------------------------------------------------------
+static int pow2_ceil(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+struct Plan {
+    int P, TS, GS, offG, offT, offD, offW, offO;
+    size_t lds_bytes;
+    bool vrow;
+    int cm_t;   // template Cm (0 = run-time)
+};
+
+static int make_plan(Plan& pl, bool backward, bool guided, int total, int K, int Ci, int Ca, int Cm, int H,
+                     bool ptrs_aligned) {
+    const int CT = Ci + Ca;
+    pl.vrow = ptrs_aligned && (Ci % 4 == 0) && (Ca % 4 == 0);
+    const bool cm_vec = (Cm % 4 == 0);
+    pl.cm_t = 0;
+    if (Cm == 1) pl.cm_t = 1;
+    else if (pl.vrow && cm_vec && (Cm == 4 || Cm == 8 || Cm == 16 || Cm == 32)) pl.cm_t = Cm;
+    // row stride of the gathered tile: 16-byte rows with an odd number of quads (bank spread for the
+    // transposed read in grad_w), or an odd float count on the scalar path.
+    if (pl.vrow) {
+        int q = CT / 4;
+        if ((q & 1) == 0) q += 1;
+        pl.TS = backward ? q * 4 : CT;
+    } else {
+        pl.TS = backward ? (CT | 1) : CT;
+    }
+    pl.GS = (pl.cm_t >= 4) ? Cm + 4 : Cm;
+    auto r4 = [](size_t v) { return (v + 3) / 4 * 4; };
+    const size_t per_pt_idx = K;
+    const size_t per_pt_g = guided ? (size_t)K * H : 0;
+    const size_t per_pt_t = (size_t)K * pl.TS;
+    const size_t per_pt_d = (backward && guided) ? (size_t)K * pl.TS : 0;
+    const size_t per_pt_w = (size_t)K * Cm;
+    const size_t per_pt_o = backward ? (size_t)CT * pl.GS : 0;
+    const size_t per_pt = per_pt_idx + per_pt_g + per_pt_t + per_pt_d + per_pt_w + per_pt_o;
+    const size_t slack = 6 * 4;   // rounding of each region to 4 floats
+    if ((per_pt + slack) * 4 > (size_t)LDS_MAX)
+        return fail(PCF_E_UNSUPPORTED, "aggregate: one point needs %zu B of LDS (K=%d Ci=%d Ca=%d Cm=%d), limit %d",
+                    (per_pt + slack) * 4, K, Ci, Ca, Cm, LDS_MAX);
+    int P = (int)((LDS_BUDGET / 4 - slack) / per_pt);
+    if (P < 1) P = 1;
+    if (P > 8) P = 8;
+    while (P > NWAVE && total / P < 1024) --P;
+    pl.P = P;
+    size_t off = r4((size_t)P * per_pt_idx);
+    pl.offG = (int)off; off = r4(off + (size_t)P * per_pt_g);
+    pl.offT = (int)off; off = r4(off + (size_t)P * per_pt_t);
+    pl.offD = (int)off; off = r4(off + (size_t)P * per_pt_d);
+    pl.offW = (int)off; off = r4(off + (size_t)P * per_pt_w);
+    pl.offO = (int)off; off = r4(off + (size_t)P * per_pt_o);
+    pl.lds_bytes = off * 4;
+    return PCF_OK;
+}
+
+template <typename KernelT>
+static int launch(KernelT kernel, const AggArgs& a, const Plan& pl, hipStream_t stream, const char* what) {
+    if (pl.lds_bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes);
+        if (e != hipSuccess) return fail(PCF_E_LAUNCH, "%s: hipFuncSetAttribute(%zu B LDS): %s", what, pl.lds_bytes,
+                                         hipGetErrorString(e));
+    }
+    const int grid = ceil_div(a.total, pl.P);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(BLOCK), pl.lds_bytes, stream, a);
+    return check_launch(what);
+}
+
+static int launch_fwd(const AggArgs& a, const Plan& pl, hipStream_t s) {
+#define PCF_FWD(CMV)                                                                   \
+    return pl.vrow ? launch(agg_fwd_kernel<CMV, true>, a, pl, s, "aggregate forward")  \
+                   : launch(agg_fwd_kernel<CMV, false>, a, pl, s, "aggregate forward")
+    switch (pl.cm_t) {
+        case 1: PCF_FWD(1);
+        case 4: return launch(agg_fwd_kernel<4, true>, a, pl, s, "aggregate forward");
+        case 8: return launch(agg_fwd_kernel<8, true>, a, pl, s, "aggregate forward");
+        case 16: return launch(agg_fwd_kernel<16, true>, a, pl, s, "aggregate forward");
+        case 32: return launch(agg_fwd_kernel<32, true>, a, pl, s, "aggregate forward");
+        default: PCF_FWD(0);
+    }
+#undef PCF_FWD
+}
+
+template <bool ATOMIC>
+static int launch_bwd_mode(const AggArgs& a, const Plan& pl, hipStream_t s) {
+#define PCF_BWD(CMV)                                                                            \
+    return pl.vrow ? launch(agg_bwd_kernel<CMV, true, ATOMIC>, a, pl, s, "aggregate backward")  \
+                   : launch(agg_bwd_kernel<CMV, false, ATOMIC>, a, pl, s, "aggregate backward")
+    switch (pl.cm_t) {
+        case 1: PCF_BWD(1);
+        case 4: return launch(agg_bwd_kernel<4, true, ATOMIC>, a, pl, s, "aggregate backward");
+        case 8: return launch(agg_bwd_kernel<8, true, ATOMIC>, a, pl, s, "aggregate backward");
+        case 16: return launch(agg_bwd_kernel<16, true, ATOMIC>, a, pl, s, "aggregate backward");
+        case 32: return launch(agg_bwd_kernel<32, true, ATOMIC>, a, pl, s, "aggregate backward");
+        default: PCF_BWD(0);
+    }
+#undef PCF_BWD
+}
+
+static int check_dims(const char* who, int B, int N, int Nout, int K, int Ci, int Ca, int Cm, int H, bool guided) {
+    PCF_REQUIRE(B >= 0 && N >= 0 && Nout >= 0, "%s: negative batch/point count (B=%d N=%d Nout=%d)", who, B, N, Nout);
+    PCF_REQUIRE(K >= 1 && Ci >= 0 && Ca >= 0 && Ci + Ca >= 1 && Cm >= 1, "%s: bad K/Ci/Ca/Cm (%d/%d/%d/%d)", who, K, Ci,
+                Ca, Cm);
+    PCF_REQUIRE(!guided || H >= 1, "%s: num_heads must be >= 1 (got %d)", who, H);
+    PCF_REQUIRE((long long)B * N < (1ll << 31) && (long long)B * Nout * K < (1ll << 31),
+                "%s: B*N or B*Nout*K does not fit 31 bits", who);
+    return PCF_OK;
+}
+
+// Forward of both operators.  guid == null -> PConv; add == null / Ca == 0 -> no appended features.
+int aggregate_forward(const float* x, const int64_t* idx, const float* guid, const float* w, const float* add,
+                      float* out, int B, int N, int Nout, int K, int Ci, int Ca, int Cm, int H, hipStream_t stream) {
+    if (int e = check_dims("aggregate forward", B, N, Nout, K, Ci, Ca, Cm, H, guid != nullptr)) return e;
+    const int total = B * Nout;
+    if (total == 0) return ok();
+    PCF_REQUIRE(x || N == 0 || Ci == 0, "aggregate forward: x is null");
+    PCF_REQUIRE(idx && w && out, "aggregate forward: null pointer (idx=%p w=%p out=%p)", (const void*)idx,
+                (const void*)w, (void*)out);
+    PCF_REQUIRE(Ca == 0 || add, "aggregate forward: Ca=%d but additional features pointer is null", Ca);
+    const bool al = aligned16(x) && aligned16(w) && aligned16(out) && (Ca == 0 || aligned16(add));
+    Plan pl;
+    if (int e = make_plan(pl, false, guid != nullptr, total, K, Ci, Ca, Cm, H, al)) return e;
+    AggArgs a{};
+    a.x = x; a.idx = idx; a.guid = guid; a.w = w; a.add = add; a.out = out;
+    a.total = total; a.N = N; a.Nout = Nout; a.K = K; a.Ci = Ci; a.Ca = Ca; a.Cm = Cm; a.H = guid ? H : 1;
+    a.P = pl.P; a.TS = pl.TS; a.GS = pl.GS;
+    a.offG = pl.offG; a.offT = pl.offT; a.offD = pl.offD; a.offW = pl.offW; a.offO = pl.offO;
+    return launch_fwd(a, pl, stream);
+}
+
+// Backward of both operators.  Exactly one of gx (atomic scatter; zeroed here) / contrib (per-edge
+// rows for csr_reduce) is non-null.
+int aggregate_backward(const float* gout, const float* x, const int64_t* idx, const float* guid, const float* w,
+                       const float* add, float* gx, float* contrib, float* gguid, float* gw, float* gadd, int B,
+                       int N, int Nout, int K, int Ci, int Ca, int Cm, int H, hipStream_t stream) {
+    if (int e = check_dims("aggregate backward", B, N, Nout, K, Ci, Ca, Cm, H, guid != nullptr)) return e;
+    const int total = B * Nout;
+    if (gx && (size_t)B * N * Ci > 0) {
+        hipError_t e = hipMemsetAsync(gx, 0, (size_t)B * N * Ci * sizeof(float), stream);
+        if (e != hipSuccess) return fail(PCF_E_LAUNCH, "aggregate backward: memset grad_x: %s", hipGetErrorString(e));
+    }
+    if (total == 0) return ok();
+    PCF_REQUIRE(gout && idx && w && gw, "aggregate backward: null pointer");
+    PCF_REQUIRE((gx != nullptr) != (contrib != nullptr) || Ci == 0, "aggregate backward: need exactly one of grad_x / contrib");
+    PCF_REQUIRE(!guid || gguid, "aggregate backward: grad_guid is null");
+    PCF_REQUIRE(Ca == 0 || (add && gadd), "aggregate backward: Ca=%d but add/grad_add pointer is null", Ca);
+    const bool al = aligned16(x) && aligned16(w) && aligned16(gout) && aligned16(gw) && (Ca == 0 || aligned16(add));
+    Plan pl;
+    if (int e = make_plan(pl, true, guid != nullptr, total, K, Ci, Ca, Cm, H, al)) return e;
+    AggArgs a{};
+    a.x = x; a.idx = idx; a.guid = guid; a.w = w; a.add = add; a.gout = gout;
+    a.gx = gx; a.contrib = contrib; a.gguid = gguid; a.gw = gw; a.gadd = gadd;
+    a.total = total; a.N = N; a.Nout = Nout; a.K = K; a.Ci = Ci; a.Ca = Ca; a.Cm = Cm; a.H = guid ? H : 1;
+    a.P = pl.P; a.TS = pl.TS; a.GS = pl.GS;
+    a.offG = pl.offG; a.offT = pl.offT; a.offD = pl.offD; a.offW = pl.offW; a.offO = pl.offO;
+    return gx ? launch_bwd_mode<true>(a, pl, stream) : launch_bwd_mode<false>(a, pl, stream);
+}
+
+int csr_reduce(const float* contrib, const int32_t* inv_n, const uint8_t* inv_k, const int32_t* inv_idx, float* gx,
+               int B, int N, int Nout, int K, int Ci, int inv_len, int inv_idx_len, hipStream_t stream) {
+    const long long rows = (long long)B * N;
+    if (rows == 0 || Ci == 0) return ok();
+    const int grid = (int)std::min<long long>((rows + NWAVE - 1) / NWAVE, 256 * 32);
+    hipLaunchKernelGGL(csr_reduce_kernel, dim3(grid), dim3(BLOCK), 0, stream, contrib, inv_n, inv_k, inv_idx, gx, B, N,
+                       Nout, K, Ci, inv_len, inv_idx_len);
+    return check_launch("csr gather-reduce");
+}
+
+}  // namespace pcf
+
+// ---- C ABI ----------------------------------------------------------------------------------------
+extern "C" {
+
+int pcf_hip_pcf_forward(const float* x, const int64_t* idx, const float* guid, const float* w, float* out, int B,
+                        int N, int Nout, int K, int Ci, int Cm, int H, void* stream) {
+    if (!guid && B * Nout > 0) return pcf::fail(PCF_E_BADARG, "pcf_forward: guidance is null");
+    return pcf::aggregate_forward(x, idx, guid, w, nullptr, out, B, N, Nout, K, Ci, 0, Cm, H, (hipStream_t)stream);
+}
+
+int pcf_hip_pcf_backward(const float* grad_out, const float* x, const int64_t* idx, const float* guid, const float* w,
+                         float* grad_x, float* grad_guid, float* grad_w, int B, int N, int Nout, int K, int Ci, int Cm,
+                         int H, void* stream) {
+    if (!guid && B * Nout > 0) return pcf::fail(PCF_E_BADARG, "pcf_backward: guidance is null");
+    if (!grad_x && (long long)B * N * Ci > 0) return pcf::fail(PCF_E_BADARG, "pcf_backward: grad_x is null");
+    return pcf::aggregate_backward(grad_out, x, idx, guid, w, nullptr, grad_x, nullptr, grad_guid, grad_w, nullptr, B, N,
+                                   Nout, K, Ci, 0, Cm, H, (hipStream_t)stream);
+}
+
+int pcf_hip_pconv_forward(const float* x, const int64_t* idx, const float* w, const float* add, float* out, int B,
+                          int N, int Nout, int K, int Ci, int Ca, int Cm, void* stream) {
+    return pcf::aggregate_forward(x, idx, nullptr, w, add, out, B, N, Nout, K, Ci, Ca, Cm, 1, (hipStream_t)stream);
+}
+
+int pcf_hip_pconv_backward(const float* grad_out, const float* x, const int64_t* idx, const float* w, const float* add,
+                           float* grad_x, float* grad_w, float* grad_add, int B, int N, int Nout, int K, int Ci, int Ca,
+                           int Cm, void* stream) {
+    if (!grad_x && (long long)B * N * Ci > 0) return pcf::fail(PCF_E_BADARG, "pconv_backward: grad_x is null");
+    return pcf::aggregate_backward(grad_out, x, idx, nullptr, w, add, grad_x, nullptr, nullptr, grad_w, grad_add, B, N,
+                                   Nout, K, Ci, Ca, Cm, 1, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,367 @@
+// k nearest neighbours over a packed batch, and the CSR transpose of a neighbour table (gfx950).
+//
+// kNN: exact brute force.  One lane = one query, which keeps its K best (distance, index) pairs
+// sorted in registers; a workgroup streams its sample's reference points through LDS in tiles and
+// every lane reads the same reference at the same time (LDS broadcast, one ds_read_b128 per
+// reference per wave).  Distances are ((rx-qx)^2 + (ry-qy)^2) + (rz-qz)^2 with one fp32 rounding per
+// operation (no fma contraction), references are visited in index order and an equal distance never
+// displaces an earlier one, so the result is the unique (distance, index)-ascending list and is
+// bit-identical to oracle/knn_ref.c.  Replaces the per-(sample, level, relation) KeOps argKmin calls
+// of knn_post_dataloader_utils.py:22-87,171-223 with one launch per (level, relation).
+//
+// CSR transpose: histogram (int atomics) -> 3-kernel exclusive scan -> atomic fill of edge ids ->
+// per-bucket sort by edge id, so every bucket lists its (query, k) pairs in ascending order whatever
+// order the atomics landed in.  Replaces count_neighbors / compute_inv_idx (a single-thread scan) /
+// fill_inverse of knn.cu:24-168, whose bucket order is run-to-run random.
+#include <algorithm>
+
+#include "pcf_common.h"
+
+namespace pcf {
+
+// =================================================================================================
+// kNN
+// =================================================================================================
+constexpr int KNN_TILE = 2048;   // reference points per LDS tile (32 KiB as float4)
+
+template <int KMAX>
+__global__ __launch_bounds__(BLOCK) void knn_kernel(const float* __restrict__ ref, const float* __restrict__ query,
+                                                    const int32_t* __restrict__ ref_off,
+                                                    const int32_t* __restrict__ query_off, int K,
+                                                    int64_t* __restrict__ out) {
+    __shared__ float4 tile[KNN_TILE];
+    const int seg = blockIdx.y;
+    const int q0 = query_off[seg], q1 = query_off[seg + 1];
+    const int r0 = ref_off[seg], r1 = ref_off[seg + 1];
+    if ((int)(blockIdx.x * BLOCK) >= q1 - q0) return;     // whole workgroup leaves together
+    const int q = q0 + blockIdx.x * BLOCK + threadIdx.x;
+    const bool active = q < q1;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    if (active) { qx = query[3 * (size_t)q]; qy = query[3 * (size_t)q + 1]; qz = query[3 * (size_t)q + 2]; }
+
+    float bd[KMAX];
+    int bi[KMAX];
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s) { bd[s] = __builtin_inff(); bi[s] = -1; }
+
+    for (int t0 = r0; t0 < r1; t0 += KNN_TILE) {
+        const int cnt = min(KNN_TILE, r1 - t0);
+        __syncthreads();
+        for (int j = threadIdx.x; j < cnt; j += BLOCK) {
+            const float* p = ref + 3 * (size_t)(t0 + j);
+            tile[j] = make_float4(p[0], p[1], p[2], 0.f);
+        }
+        __syncthreads();
+        if (active) {
+            for (int j = 0; j < cnt; ++j) {
+                const float4 r = tile[j];
+                const float dx = __fsub_rn(r.x, qx), dy = __fsub_rn(r.y, qy), dz = __fsub_rn(r.z, qz);
+                const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+                if (d < bd[KMAX - 1]) {
+                    const int id = t0 + j;
+#pragma unroll
+                    for (int s = KMAX - 1; s > 0; --s) {
+                        const bool shift = d < bd[s - 1];       // the old element s-1 moves to s
+                        const bool here = d < bd[s];            // ... otherwise d lands at s if it beats the old s
+                        bi[s] = shift ? bi[s - 1] : (here ? id : bi[s]);
+                        bd[s] = shift ? bd[s - 1] : (here ? d : bd[s]);
+                    }
+                    if (d < bd[0]) { bd[0] = d; bi[0] = id; }
+                }
+            }
+        }
+    }
+    if (active) {
+#pragma unroll
+        for (int s = 0; s < KMAX; ++s)
+            if (s < K) out[(size_t)q * K + s] = (int64_t)bi[s];
+    }
+}
+
+// =================================================================================================
+// CSR transpose
+// =================================================================================================
+__global__ __launch_bounds__(BLOCK) void csr_count_kernel(const int64_t* __restrict__ idx, int32_t* __restrict__ counts,
+                                                          long long edges, int total_points) {
+    for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < edges; e += (long long)gridDim.x * BLOCK) {
+        const int64_t t = idx[e];
+        if (t >= 0 && t < total_points) atomicAdd(&counts[t], 1);
+    }
+}
+
+constexpr int SCAN_CHUNK = 1024;   // elements per workgroup (4 per thread)
+
+__device__ __forceinline__ int block_exclusive_scan(int v, int* total) {
+    __shared__ int wave_sums[NWAVE];
+    const int lane = lane_id(), wave = wave_id();
+    int inc = v;
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+        const int t = __shfl_up(inc, off, WAVE);
+        if (lane >= off) inc += t;
+    }
+    if (lane == WAVE - 1) wave_sums[wave] = inc;
+    __syncthreads();
+    int base = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < NWAVE; ++w) {
+        const int s = wave_sums[w];
+        if (w < wave) base += s;
+        all += s;
+    }
+    __syncthreads();
+    *total = all;
+    return base + inc - v;
+}
+
+// phase a: per-chunk totals
+__global__ __launch_bounds__(BLOCK) void scan_chunk_sums_kernel(const int32_t* __restrict__ counts,
+                                                                int32_t* __restrict__ chunk_sums, int n) {
+    const int base = blockIdx.x * SCAN_CHUNK + threadIdx.x * 4;
+    int v = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (base + i < n) v += counts[base + i];
+    int total;
+    block_exclusive_scan(v, &total);
+    if (threadIdx.x == 0) chunk_sums[blockIdx.x] = total;
+}
+
+// phase b: exclusive scan of the chunk totals by one workgroup
+__global__ __launch_bounds__(BLOCK) void scan_chunk_offsets_kernel(int32_t* __restrict__ chunk_sums, int nchunks) {
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < nchunks; c0 += BLOCK) {
+        const int i = c0 + threadIdx.x;
+        const int v = i < nchunks ? chunk_sums[i] : 0;
+        int total;
+        const int ex = block_exclusive_scan(v, &total);
+        const int cbase = carry;
+        if (i < nchunks) chunk_sums[i] = cbase + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry = cbase + total;
+        __syncthreads();
+    }
+}
+
+// phase c: inv_idx[i] = exclusive prefix of counts; inv_idx[n] = grand total
+__global__ __launch_bounds__(BLOCK) void scan_write_kernel(const int32_t* __restrict__ counts,
+                                                           const int32_t* __restrict__ chunk_offsets,
+                                                           int32_t* __restrict__ inv_idx, int n) {
+    const int base = blockIdx.x * SCAN_CHUNK + threadIdx.x * 4;
+    int c[4];
+    int v = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { c[i] = (base + i < n) ? counts[base + i] : 0; v += c[i]; }
+    int total;
+    int run = chunk_offsets[blockIdx.x] + block_exclusive_scan(v, &total);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (base + i < n) inv_idx[base + i] = run;
+        run += c[i];
+        if (base + i == n - 1) inv_idx[n] = run;
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void csr_fill_kernel(const int64_t* __restrict__ idx,
+                                                         const int32_t* __restrict__ inv_idx,
+                                                         int32_t* __restrict__ cursor, uint32_t* __restrict__ keys,
+                                                         long long edges, int total_points) {
+    for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < edges; e += (long long)gridDim.x * BLOCK) {
+        const int64_t t = idx[e];
+        if (t >= 0 && t < total_points) {
+            const int pos = atomicAdd(&cursor[t], 1);
+            keys[inv_idx[t] + pos] = (uint32_t)e;
+        }
+    }
+}
+
+__device__ __forceinline__ void emit(uint32_t key, int pos, int K, int32_t* inv_n, uint8_t* inv_k) {
+    const uint32_t n = key / (uint32_t)K;
+    inv_n[pos] = (int32_t)n;
+    inv_k[pos] = (uint8_t)(key - n * (uint32_t)K);
+}
+
+// Buckets of <= 64 entries: one wave each, bitonic network over the lanes.  Larger buckets are
+// appended to a work list for csr_sort_large_kernel.
+__global__ __launch_bounds__(BLOCK) void csr_sort_small_kernel(const uint32_t* __restrict__ keys,
+                                                               const int32_t* __restrict__ inv_idx, int total_points,
+                                                               int K, int32_t* __restrict__ inv_n,
+                                                               uint8_t* __restrict__ inv_k, int32_t* __restrict__ big_list,
+                                                               int32_t* __restrict__ big_count) {
+    const int lane = lane_id();
+    for (int t = blockIdx.x * NWAVE + wave_id(); t < total_points; t += gridDim.x * NWAVE) {
+        const int beg = inv_idx[t], end = inv_idx[t + 1];
+        const int d = end - beg;
+        if (d <= 0) continue;
+        if (d > WAVE) {
+            if (lane == 0) big_list[atomicAdd(big_count, 1)] = t;
+            continue;
+        }
+        uint32_t v = lane < d ? keys[beg + lane] : 0xffffffffu;
+#pragma unroll
+        for (int k = 2; k <= WAVE; k <<= 1) {
+#pragma unroll
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                const uint32_t o = __shfl_xor(v, j, WAVE);
+                const bool up = (lane & k) == 0;
+                const bool low = (lane & j) == 0;
+                v = (low == up) ? min(v, o) : max(v, o);
+            }
+        }
+        if (lane < d) emit(v, beg + lane, K, inv_n, inv_k);
+    }
+}
+
+constexpr int SORT_LDS = 4096;   // keys a workgroup sorts in LDS
+
+// Buckets of > 64 entries: one workgroup each.  Up to SORT_LDS keys: bitonic sort in LDS.  Beyond
+// that (adversarial tables only): rank by counting, O(d^2 / 256) -- slow but exact.
+__global__ __launch_bounds__(BLOCK) void csr_sort_large_kernel(const uint32_t* __restrict__ keys,
+                                                               const int32_t* __restrict__ inv_idx, int K,
+                                                               int32_t* __restrict__ inv_n, uint8_t* __restrict__ inv_k,
+                                                               const int32_t* __restrict__ big_list,
+                                                               const int32_t* __restrict__ big_count) {
+    __shared__ uint32_t s[SORT_LDS];
+    const int nbig = *big_count;
+    for (int w = blockIdx.x; w < nbig; w += gridDim.x) {
+        const int t = big_list[w];
+        const int beg = inv_idx[t], d = inv_idx[t + 1] - beg;
+        if (d <= SORT_LDS) {
+            int n2 = 1;
+            while (n2 < d) n2 <<= 1;
+            __syncthreads();
+            for (int i = threadIdx.x; i < n2; i += BLOCK) s[i] = i < d ? keys[beg + i] : 0xffffffffu;
+            __syncthreads();
+            for (int k = 2; k <= n2; k <<= 1) {
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int i = threadIdx.x; i < n2; i += BLOCK) {
+                        const int p = i ^ j;
+                        if (p > i) {
+                            const uint32_t a = s[i], b = s[p];
+                            const bool up = (i & k) == 0;
+                            if ((a > b) == up) { s[i] = b; s[p] = a; }
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+            for (int i = threadIdx.x; i < d; i += BLOCK) emit(s[i], beg + i, K, inv_n, inv_k);
+        } else {
+            for (int i = threadIdx.x; i < d; i += BLOCK) {
+                const uint32_t mine = keys[beg + i];
+                int rank = 0;
+                for (int j = 0; j < d; ++j) rank += keys[beg + j] < mine;
+                emit(mine, beg + rank, K, inv_n, inv_k);
+            }
+        }
+    }
+}
+
+struct CsrWs {
+    size_t off_counts, off_chunks, off_keys, off_big, off_bigcount, bytes;
+    int nchunks;
+};
+static CsrWs csr_plan(int Nq, int K, int total_points) {
+    CsrWs w{};
+    w.nchunks = std::max(1, ceil_div(total_points, SCAN_CHUNK));
+    size_t off = 0;
+    w.off_counts = off;   off = align_up(off + (size_t)std::max(total_points, 1) * 4, 256);
+    w.off_chunks = off;   off = align_up(off + (size_t)w.nchunks * 4, 256);
+    w.off_keys = off;     off = align_up(off + (size_t)Nq * K * 4 + 4, 256);
+    w.off_big = off;      off = align_up(off + (size_t)std::max(total_points, 1) * 4, 256);
+    w.off_bigcount = off; off = align_up(off + 4, 256);
+    w.bytes = off;
+    return w;
+}
+
+}  // namespace pcf
+
+extern "C" {
+
+int pcf_hip_knn(const float* ref, const float* query, const int32_t* ref_off, const int32_t* query_off, int n_seg,
+                int max_queries_per_seg, int K, int64_t* out, void* stream) {
+    using namespace pcf;
+    PCF_REQUIRE(K >= 1 && K <= 64, "knn: K must be in [1,64] (got %d)", K);
+    PCF_REQUIRE(n_seg >= 0 && max_queries_per_seg >= 0, "knn: negative size");
+    if (n_seg == 0 || max_queries_per_seg == 0) return ok();
+    PCF_REQUIRE(ref && query && ref_off && query_off && out, "knn: null pointer");
+    PCF_REQUIRE(n_seg <= 65535, "knn: more than 65535 samples in one packed batch");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(ceil_div(max_queries_per_seg, BLOCK), n_seg);
+    if (K <= 8) hipLaunchKernelGGL(knn_kernel<8>, grid, dim3(BLOCK), 0, s, ref, query, ref_off, query_off, K, out);
+    else if (K <= 16) hipLaunchKernelGGL(knn_kernel<16>, grid, dim3(BLOCK), 0, s, ref, query, ref_off, query_off, K, out);
+    else if (K <= 32) hipLaunchKernelGGL(knn_kernel<32>, grid, dim3(BLOCK), 0, s, ref, query, ref_off, query_off, K, out);
+    else hipLaunchKernelGGL(knn_kernel<64>, grid, dim3(BLOCK), 0, s, ref, query, ref_off, query_off, K, out);
+    return check_launch("kNN");
+}
+
+size_t pcf_hip_knn_inverse_workspace_bytes(int B, int Nq, int K, int total_points) {
+    (void)B;
+    if (Nq < 0 || K < 0 || total_points < 0) return 0;
+    return pcf::csr_plan(Nq, K, total_points).bytes;
+}
+
+int pcf_hip_knn_inverse(const int64_t* idx, int32_t* inv_neighbors, uint8_t* inv_k, int32_t* inv_idx, void* workspace,
+                        size_t workspace_bytes, int B, int Nq, int K, int total_points, void* stream) {
+    using namespace pcf;
+    PCF_REQUIRE(B >= 0 && Nq >= 0 && total_points >= 0, "knn_inverse: negative size");
+    PCF_REQUIRE(K >= 1 && K <= 255, "knn_inverse: K must be in [1,255] (inv_k is uint8), got %d", K);
+    PCF_REQUIRE((long long)Nq * K < (1ll << 31), "knn_inverse: Nq*K does not fit 31 bits");
+    const CsrWs w = csr_plan(Nq, K, total_points);
+    PCF_REQUIRE(workspace_bytes >= w.bytes && workspace && aligned16(workspace),
+                "knn_inverse: workspace too small or misaligned (%zu < %zu)", workspace_bytes, w.bytes);
+    PCF_REQUIRE(inv_idx && (B * (long long)Nq == 0 || (idx && inv_neighbors && inv_k)), "knn_inverse: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    char* ws = static_cast<char*>(workspace);
+    int32_t* counts = reinterpret_cast<int32_t*>(ws + w.off_counts);
+    int32_t* chunks = reinterpret_cast<int32_t*>(ws + w.off_chunks);
+    uint32_t* keys = reinterpret_cast<uint32_t*>(ws + w.off_keys);
+    int32_t* big = reinterpret_cast<int32_t*>(ws + w.off_big);
+    int32_t* bigc = reinterpret_cast<int32_t*>(ws + w.off_bigcount);
+    const long long edges = (long long)Nq * K;
+    const int egrid = (int)std::max<long long>(1, std::min<long long>((edges + BLOCK - 1) / BLOCK, 4096));
+#define PCF_HIP(call)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) return fail(PCF_E_LAUNCH, "knn_inverse: %s", hipGetErrorString(e_)); \
+    } while (0)
+    for (int b = 0; b < B; ++b) {
+        const int64_t* ib = idx + (size_t)b * edges;
+        int32_t* nb = inv_neighbors + (size_t)b * edges;
+        uint8_t* kb = inv_k + (size_t)b * edges;
+        int32_t* xb = inv_idx + (size_t)b * (total_points + 1);
+        if (edges) {
+            PCF_HIP(hipMemsetAsync(nb, 0, (size_t)edges * 4, s));
+            PCF_HIP(hipMemsetAsync(kb, 0, (size_t)edges, s));
+        }
+        if (total_points == 0) {
+            PCF_HIP(hipMemsetAsync(xb, 0, 4, s));
+            continue;
+        }
+        PCF_HIP(hipMemsetAsync(counts, 0, (size_t)total_points * 4, s));
+        PCF_HIP(hipMemsetAsync(bigc, 0, 4, s));
+        if (edges) {
+            hipLaunchKernelGGL(csr_count_kernel, dim3(egrid), dim3(BLOCK), 0, s, ib, counts, edges, total_points);
+            if (int e = check_launch("knn_inverse histogram")) return e;
+        }
+        hipLaunchKernelGGL(scan_chunk_sums_kernel, dim3(w.nchunks), dim3(BLOCK), 0, s, counts, chunks, total_points);
+        hipLaunchKernelGGL(scan_chunk_offsets_kernel, dim3(1), dim3(BLOCK), 0, s, chunks, w.nchunks);
+        hipLaunchKernelGGL(scan_write_kernel, dim3(w.nchunks), dim3(BLOCK), 0, s, counts, chunks, xb, total_points);
+        if (int e = check_launch("knn_inverse scan")) return e;
+        if (edges) {
+            PCF_HIP(hipMemsetAsync(counts, 0, (size_t)total_points * 4, s));
+            hipLaunchKernelGGL(csr_fill_kernel, dim3(egrid), dim3(BLOCK), 0, s, ib, xb, counts, keys, edges, total_points);
+            const int sgrid = std::max(1, std::min(ceil_div(total_points, NWAVE), 8192));
+            hipLaunchKernelGGL(csr_sort_small_kernel, dim3(sgrid), dim3(BLOCK), 0, s, keys, xb, total_points, K, nb, kb,
+                               big, bigc);
+            hipLaunchKernelGGL(csr_sort_large_kernel, dim3(1024), dim3(BLOCK), 0, s, keys, xb, K, nb, kb, big, bigc);
+            if (int e = check_launch("knn_inverse fill/sort")) return e;
+        }
+    }
+#undef PCF_HIP
+    return ok();
+}
+
+}  // extern "C"

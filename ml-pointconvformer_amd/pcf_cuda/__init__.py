@@ -1,0 +1,353 @@
+"""``pcf_cuda`` for AMD Instinct MI355X: the reference's operator module, re-implemented on HIP.
+
+Drop-in for the torch extension the reference builds from ``cpp_wrappers/cpp_pcf_kernel``
+(``pcf_cuda.cpp:9-19``): same module name, the same nine functions with the same argument
+order, dtypes, shapes and return arity, so ``layer_utils.py`` / ``util/common_util.py`` /
+``train_ScanNet_DDP_WarmUP.py`` import and call it unchanged.  Put this package's parent
+directory (``ml-pointconvformer_amd/``) on ``PYTHONPATH``.
+
+Underneath is ``libpcf_hip.so`` (C ABI in ``include/pcf_hip.h``, hand-written gfx950 kernels in
+``csrc/``), bound here with ctypes: tensors go down as raw device pointers, work is enqueued
+on torch's *current* HIP stream of the tensors' device (the reference uses the legacy default
+stream and no device guard), outputs are allocated with torch.  There is no CPU
+or PyTorch fallback: if the library is missing the import fails, and every call raises on
+non-device tensors exactly as the reference's CHECK_INPUT does (``pcf.h:14-24``).
+
+Differences from the reference, all deliberate:
+  * backward functions return the true adjoint of the forward (forward channel layout
+    ``c*C_mid + m``); the reference's CUDA backward indexes ``m*C_in + c``.
+  * ``compute_knn_inverse`` orders each CSR bucket by (query, k); the reference's order is
+    whatever its atomics produced.
+  * ``pconv_linear_opt_backward`` uses the CSR for every input row (deterministic grad_input)
+    and performs no device->host sync (the reference syncs twice per call, pconv_ops.cu:887-889).
+  * fp32 only (the reference's CUTLASS path is fp32-only too; its older kernels also took fp64).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+
+__all__ = [
+    'pcf_forward', 'pcf_backward', 'pconv_forward', 'pconv_backward', 'pconv_linear_forward',
+    'pconv_linear_backward', 'pconv_linear_opt_backward', 'compute_knn_inverse',
+    'pconv_linear_cutlass_forward', 'knn_packed', 'gemm_nt', 'library_path', 'version',
+]
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.environ.get('PCF_HIP_LIBRARY', os.path.join(_HERE, 'libpcf_hip.so'))
+
+if not os.path.exists(_LIB_PATH):
+    raise ImportError(
+        f'pcf_cuda: {_LIB_PATH} not found. Build it with `make -C ml-pointconvformer_amd/csrc` '
+        '(or __graft_entry__.build()); there is no fallback implementation.')
+_lib = ctypes.CDLL(_LIB_PATH)
+
+_P, _I, _Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+
+
+def _sig(name, argtypes, restype=_I):
+    fn = getattr(_lib, name)
+    fn.argtypes = argtypes
+    fn.restype = restype
+    return fn
+
+
+_version = _sig('pcf_hip_version', [], ctypes.c_char_p)
+_last_error = _sig('pcf_hip_last_error', [], ctypes.c_char_p)
+_pcf_fwd = _sig('pcf_hip_pcf_forward', [_P] * 5 + [_I] * 7 + [_P])
+_pcf_bwd = _sig('pcf_hip_pcf_backward', [_P] * 8 + [_I] * 7 + [_P])
+_pconv_fwd = _sig('pcf_hip_pconv_forward', [_P] * 5 + [_I] * 7 + [_P])
+_pconv_bwd = _sig('pcf_hip_pconv_backward', [_P] * 8 + [_I] * 7 + [_P])
+_pl_fwd = _sig('pcf_hip_pconv_linear_forward', [_P] * 8 + [_I] * 8 + [_P])
+_pl_bwd_ws = _sig('pcf_hip_pconv_linear_backward_workspace_bytes', [_I] * 8, _Z)
+_pl_bwd = _sig('pcf_hip_pconv_linear_backward', [_P] * 13 + [_Z] + [_I] * 8 + [_P])
+_plo_bwd_ws = _sig('pcf_hip_pconv_linear_opt_backward_workspace_bytes', [_I] * 8, _Z)
+_plo_bwd = _sig('pcf_hip_pconv_linear_opt_backward', [_P] * 16 + [_Z] + [_I] * 10 + [_P])
+_inv_ws = _sig('pcf_hip_knn_inverse_workspace_bytes', [_I] * 4, _Z)
+_inv = _sig('pcf_hip_knn_inverse', [_P] * 5 + [_Z] + [_I] * 4 + [_P])
+_knn = _sig('pcf_hip_knn', [_P] * 4 + [_I] * 3 + [_P] * 2)
+_gemm_nt = _sig('pcf_hip_gemm_nt', [_P] * 4 + [_I] * 3 + [_P])
+
+
+def library_path() -> str:
+    return _LIB_PATH
+
+
+def version() -> str:
+    return _version().decode()
+
+
+# ---- argument checks: same conditions and wording as CHECK_INPUT (pcf.h:14-24) -----------------
+def _check_input(t, name, dtype=None):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f'{name} must be a torch.Tensor')
+    if not t.is_cuda:
+        raise RuntimeError(f'{name} must be a CUDA tensor')
+    if not t.is_contiguous():
+        raise RuntimeError(f'{name} must be contiguous')
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f'{name} must be {dtype}, got {t.dtype}')
+
+
+def _floats(**tensors):
+    for name, t in tensors.items():
+        _check_input(t, name, torch.float32)
+
+
+def _ptr(t):
+    return None if t is None or t.numel() == 0 else t.data_ptr()
+
+
+def _stream(dev):
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _call(fn, *args):
+    rc = fn(*args)
+    if rc != 0:
+        raise RuntimeError(f'pcf_cuda: {_last_error().decode()} (code {rc})')
+
+
+def _dims(input, neighbor_inds, weights):
+    if input.dim() != 3 or neighbor_inds.dim() != 3 or weights.dim() != 4:
+        raise RuntimeError('pcf_cuda: expected input [B,N,C], neighbor_inds [B,Nout,K], weights [B,Nout,K,C_mid]')
+    B, N, Ci = input.shape
+    Bn, Nout, K = neighbor_inds.shape
+    if Bn != B or tuple(weights.shape[:3]) != (B, Nout, K):
+        raise RuntimeError('pcf_cuda: batch / point / neighbour dimensions of the arguments disagree')
+    return B, N, Nout, K, Ci, weights.shape[3]
+
+
+def _same_device(*ts):
+    dev = ts[0].device
+    for t in ts:
+        if t is not None and t.device != dev:
+            raise RuntimeError('pcf_cuda: all tensors must live on the same device')
+    return dev
+
+
+# ---- pcf_forward / pcf_backward  (pcf_cuda.cpp:10-11) -------------------------------------------
+def pcf_forward(input, neighbor_inds, guidance, weights):
+    _floats(input=input, guidance=guidance, weights=weights)
+    _check_input(neighbor_inds, 'neighbor_inds', torch.int64)
+    B, N, Nout, K, Ci, Cm = _dims(input, neighbor_inds, weights)
+    if guidance.dim() != 4 or tuple(guidance.shape[:3]) != (B, Nout, K):
+        raise RuntimeError('pcf_cuda: guidance must be [B,Nout,K,num_heads]')
+    H = guidance.shape[3]
+    dev = _same_device(input, neighbor_inds, guidance, weights)
+    out = torch.empty(B, Nout, Ci * Cm, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _call(_pcf_fwd, _ptr(input), _ptr(neighbor_inds), _ptr(guidance), _ptr(weights), _ptr(out),
+              B, N, Nout, K, Ci, Cm, H, _stream(dev))
+    return out
+
+
+def pcf_backward(grad_output, input, neighbor_inds, guidance, weights):
+    # the reference forgets CHECK_INPUT(input) here (src/pcf.cu:33-36); checking it is harmless
+    _floats(grad_output=grad_output, input=input, guidance=guidance, weights=weights)
+    _check_input(neighbor_inds, 'neighbor_inds', torch.int64)
+    B, N, Nout, K, Ci, Cm = _dims(input, neighbor_inds, weights)
+    H = guidance.shape[3]
+    if grad_output.numel() != B * Nout * Ci * Cm:
+        raise RuntimeError('pcf_cuda: grad_output must be [B,Nout,C_in*C_mid]')
+    dev = _same_device(grad_output, input, neighbor_inds, guidance, weights)
+    grad_input = torch.empty_like(input)
+    grad_guidance = torch.empty_like(guidance)
+    grad_weights = torch.empty_like(weights)
+    with torch.cuda.device(dev):
+        _call(_pcf_bwd, _ptr(grad_output), _ptr(input), _ptr(neighbor_inds), _ptr(guidance), _ptr(weights),
+              _ptr(grad_input), _ptr(grad_guidance), _ptr(grad_weights), B, N, Nout, K, Ci, Cm, H, _stream(dev))
+    return [grad_input, grad_guidance, grad_weights]
+
+
+# ---- pconv_forward / pconv_backward  (pcf_cuda.cpp:12,14) -------------------------------------
+def _add_dims(additional_features, B, Nout, K):
+    if additional_features.dim() != 4 or tuple(additional_features.shape[:3]) != (B, Nout, K):
+        raise RuntimeError('pcf_cuda: additional_features must be [B,Nout,K,C_add] (C_add may be 0)')
+    return additional_features.shape[3]
+
+
+def pconv_forward(input, neighbor_inds, weights, additional_features):
+    _floats(input=input, weights=weights, additional_features=additional_features)
+    _check_input(neighbor_inds, 'neighbor_inds', torch.int64)
+    B, N, Nout, K, Ci, Cm = _dims(input, neighbor_inds, weights)
+    Ca = _add_dims(additional_features, B, Nout, K)
+    dev = _same_device(input, neighbor_inds, weights, additional_features)
+    out = torch.empty(B, Nout, (Ci + Ca) * Cm, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _call(_pconv_fwd, _ptr(input), _ptr(neighbor_inds), _ptr(weights), _ptr(additional_features), _ptr(out),
+              B, N, Nout, K, Ci, Ca, Cm, _stream(dev))
+    return out
+
+
+def pconv_backward(grad_output, input, neighbor_inds, weights, additional_features):
+    _floats(grad_output=grad_output, input=input, weights=weights, additional_features=additional_features)
+    _check_input(neighbor_inds, 'neighbor_inds', torch.int64)
+    B, N, Nout, K, Ci, Cm = _dims(input, neighbor_inds, weights)
+    Ca = _add_dims(additional_features, B, Nout, K)
+    if grad_output.numel() != B * Nout * (Ci + Ca) * Cm:
+        raise RuntimeError('pcf_cuda: grad_output must be [B,Nout,(C_in+C_add)*C_mid]')
+    dev = _same_device(grad_output, input, neighbor_inds, weights, additional_features)
+    grad_input = torch.empty_like(input)
+    grad_weights = torch.empty_like(weights)
+    grad_additional = torch.empty_like(additional_features)
+    with torch.cuda.device(dev):
+        _call(_pconv_bwd, _ptr(grad_output), _ptr(input), _ptr(neighbor_inds), _ptr(weights),
+              _ptr(additional_features), _ptr(grad_input), _ptr(grad_weights), _ptr(grad_additional),
+              B, N, Nout, K, Ci, Ca, Cm, _stream(dev))
+    return [grad_input, grad_weights, grad_additional]
+
+
+# ---- fused aggregate + linear  (pcf_cuda.cpp:13,15,16,18) --------------------------------------
+def _linear_dims(linear_weights, Ci, Ca, Cm):
+    if linear_weights.dim() != 2 or linear_weights.shape[1] != (Ci + Ca) * Cm:
+        raise RuntimeError('pcf_cuda: linear_weights must be [C_out, (C_in+C_add)*C_mid]')
+    return linear_weights.shape[0]
+
+
+def pconv_linear_forward(input, neighbor_inds, weights, additional_features, linear_weights, linear_bias):
+    _floats(input=input, weights=weights, additional_features=additional_features,
+            linear_weights=linear_weights, linear_bias=linear_bias)
+    _check_input(neighbor_inds, 'neighbor_inds', torch.int64)
+    B, N, Nout, K, Ci, Cm = _dims(input, neighbor_inds, weights)
+    Ca = _add_dims(additional_features, B, Nout, K)
+    Co = _linear_dims(linear_weights, Ci, Ca, Cm)
+    if linear_bias.numel() != Co:
+        raise RuntimeError('pcf_cuda: linear_bias must be [C_out]')
+    dev = _same_device(input, neighbor_inds, weights, additional_features, linear_weights, linear_bias)
+    out = torch.empty(B, Nout, Co, dtype=torch.float32, device=dev)
+    pconv_out = torch.empty(B, Nout, (Ci + Ca) * Cm, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _call(_pl_fwd, _ptr(input), _ptr(neighbor_inds), _ptr(weights), _ptr(additional_features),
+              _ptr(linear_weights), _ptr(linear_bias), _ptr(out), _ptr(pconv_out),
+              B, N, Nout, K, Ci, Ca, Cm, Co, _stream(dev))
+    return [out, pconv_out]
+
+
+# The reference exports a second forward built on CUTLASS GEMMs; on MI355X both names are the
+# same MFMA path.
+pconv_linear_cutlass_forward = pconv_linear_forward
+
+
+def _workspace(nbytes, dev):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=dev)
+
+
+def pconv_linear_backward(grad_output, input, neighbor_inds, weights, additional_features, linear_weights,
+                          pconv_output):
+    _floats(grad_output=grad_output, input=input, weights=weights, additional_features=additional_features,
+            linear_weights=linear_weights, pconv_output=pconv_output)
+    _check_input(neighbor_inds, 'neighbor_inds', torch.int64)
+    B, N, Nout, K, Ci, Cm = _dims(input, neighbor_inds, weights)
+    Ca = _add_dims(additional_features, B, Nout, K)
+    Co = _linear_dims(linear_weights, Ci, Ca, Cm)
+    if grad_output.numel() != B * Nout * Co or pconv_output.numel() != B * Nout * (Ci + Ca) * Cm:
+        raise RuntimeError('pcf_cuda: grad_output must be [B,Nout,C_out] and pconv_output [B,Nout,(C_in+C_add)*C_mid]')
+    dev = _same_device(grad_output, input, neighbor_inds, weights, additional_features, linear_weights, pconv_output)
+    grad_input = torch.empty_like(input)
+    grad_weights = torch.empty_like(weights)
+    grad_additional = torch.empty_like(additional_features)
+    grad_linear_weights = torch.empty_like(linear_weights)
+    grad_linear_bias = torch.empty(Co, dtype=torch.float32, device=dev)
+    nbytes = _pl_bwd_ws(B, N, Nout, K, Ci, Ca, Cm, Co)
+    ws = _workspace(nbytes, dev)
+    with torch.cuda.device(dev):
+        _call(_pl_bwd, _ptr(grad_output), _ptr(input), _ptr(neighbor_inds), _ptr(weights), _ptr(additional_features),
+              _ptr(linear_weights), _ptr(pconv_output), _ptr(grad_input), _ptr(grad_weights), _ptr(grad_additional),
+              _ptr(grad_linear_weights), _ptr(grad_linear_bias), ws.data_ptr(), nbytes,
+              B, N, Nout, K, Ci, Ca, Cm, Co, _stream(dev))
+    return [grad_input, grad_weights, grad_additional, grad_linear_weights, grad_linear_bias]
+
+
+def pconv_linear_opt_backward(grad_output, input, inverse_neighbor, inverse_neighbor_k, inverse_neighbor_idx,
+                              neighbor_inds, weights, additional_features, linear_weights, pconv_output):
+    _floats(grad_output=grad_output, input=input, weights=weights, additional_features=additional_features,
+            linear_weights=linear_weights, pconv_output=pconv_output)
+    _check_input(neighbor_inds, 'neighbor_inds', torch.int64)
+    _check_input(inverse_neighbor, 'inverse_neighbor', torch.int32)
+    _check_input(inverse_neighbor_k, 'inverse_neighbor_k', torch.uint8)
+    _check_input(inverse_neighbor_idx, 'inverse_neighbor_idx', torch.int32)
+    B, N, Nout, K, Ci, Cm = _dims(input, neighbor_inds, weights)
+    Ca = _add_dims(additional_features, B, Nout, K)
+    Co = _linear_dims(linear_weights, Ci, Ca, Cm)
+    if grad_output.numel() != B * Nout * Co or pconv_output.numel() != B * Nout * (Ci + Ca) * Cm:
+        raise RuntimeError('pcf_cuda: grad_output must be [B,Nout,C_out] and pconv_output [B,Nout,(C_in+C_add)*C_mid]')
+    if inverse_neighbor.dim() != 2 or inverse_neighbor_k.shape != inverse_neighbor.shape \
+            or inverse_neighbor_idx.dim() != 2 or inverse_neighbor.shape[0] != B or inverse_neighbor_idx.shape[0] != B:
+        raise RuntimeError('pcf_cuda: inverse index tensors must be [B,L], [B,L] and [B,>=N+1]')
+    inv_len, inv_idx_len = inverse_neighbor.shape[1], inverse_neighbor_idx.shape[1]
+    dev = _same_device(grad_output, input, inverse_neighbor, inverse_neighbor_k, inverse_neighbor_idx, neighbor_inds,
+                       weights, additional_features, linear_weights, pconv_output)
+    grad_input = torch.empty_like(input)
+    grad_weights = torch.empty_like(weights)
+    grad_additional = torch.empty_like(additional_features)
+    grad_linear_weights = torch.empty_like(linear_weights)
+    grad_linear_bias = torch.empty(Co, dtype=torch.float32, device=dev)
+    nbytes = _plo_bwd_ws(B, N, Nout, K, Ci, Ca, Cm, Co)
+    ws = _workspace(nbytes, dev)
+    with torch.cuda.device(dev):
+        _call(_plo_bwd, _ptr(grad_output), _ptr(input), _ptr(inverse_neighbor), _ptr(inverse_neighbor_k),
+              _ptr(inverse_neighbor_idx), _ptr(neighbor_inds), _ptr(weights), _ptr(additional_features),
+              _ptr(linear_weights), _ptr(pconv_output), _ptr(grad_input), _ptr(grad_weights), _ptr(grad_additional),
+              _ptr(grad_linear_weights), _ptr(grad_linear_bias), ws.data_ptr(), nbytes,
+              B, N, Nout, K, Ci, Ca, Cm, Co, inv_len, inv_idx_len, _stream(dev))
+    return [grad_input, grad_weights, grad_additional, grad_linear_weights, grad_linear_bias]
+
+
+# ---- compute_knn_inverse  (pcf_cuda.cpp:17; src/pcf.cu:124-131 checks device + contiguity only) --
+def compute_knn_inverse(neighbor_inds, total_points):
+    _check_input(neighbor_inds, 'neighbor_inds', torch.int64)
+    if neighbor_inds.dim() != 3:
+        raise RuntimeError('pcf_cuda: neighbor_inds must be [B,N,K]')
+    B, Nq, K = neighbor_inds.shape
+    total_points = int(total_points)
+    dev = neighbor_inds.device
+    inv_neighbors = torch.empty(B, Nq * K, dtype=torch.int32, device=dev)
+    inv_k = torch.empty(B, Nq * K, dtype=torch.uint8, device=dev)
+    inv_idx = torch.empty(B, total_points + 1, dtype=torch.int32, device=dev)
+    nbytes = _inv_ws(B, Nq, K, total_points)
+    ws = _workspace(nbytes, dev)
+    with torch.cuda.device(dev):
+        _call(_inv, _ptr(neighbor_inds), _ptr(inv_neighbors), _ptr(inv_k), inv_idx.data_ptr(), ws.data_ptr(), nbytes,
+              B, Nq, K, total_points, _stream(dev))
+    return [inv_neighbors, inv_k, inv_idx]
+
+
+# ---- extras beyond the reference's nine (used by knn_post_dataloader_utils and the tests) --------
+def knn_packed(ref, query, ref_offsets, query_offsets, K):
+    """K nearest refs (own sample only) for every query of a packed batch.
+
+    ref [Nr,3] f32, query [Nq,3] f32 device tensors; ref_offsets / query_offsets int32 [S+1]
+    device tensors of per-sample prefix offsets.  Returns int64 [Nq,K] of packed ref indices,
+    (distance, index) ascending; -1 where a sample has fewer than K refs."""
+    _floats(ref=ref, query=query)
+    _check_input(ref_offsets, 'ref_offsets', torch.int32)
+    _check_input(query_offsets, 'query_offsets', torch.int32)
+    if ref.dim() != 2 or ref.shape[1] != 3 or query.dim() != 2 or query.shape[1] != 3:
+        raise RuntimeError('pcf_cuda: ref and query must be [n,3]')
+    S = ref_offsets.numel() - 1
+    if S < 0 or query_offsets.numel() != S + 1:
+        raise RuntimeError('pcf_cuda: offset tensors must both be [num_samples+1]')
+    dev = _same_device(ref, query, ref_offsets, query_offsets)
+    out = torch.empty(query.shape[0], K, dtype=torch.int64, device=dev)
+    # the widest sample bounds the grid; a host-side upper bound avoids a device->host sync
+    max_q = query.shape[0]
+    with torch.cuda.device(dev):
+        _call(_knn, _ptr(ref), _ptr(query), ref_offsets.data_ptr(), query_offsets.data_ptr(), S, max_q, int(K),
+              _ptr(out), _stream(dev))
+    return out
+
+
+def gemm_nt(a, b, bias=None):
+    """a [M,Kd] . b[N,Kd]^T (+ bias[N]) on the fp32 MFMA path (exposed for tests / roofline)."""
+    _floats(a=a, b=b)
+    if bias is not None:
+        _floats(bias=bias)
+    M, Kd = a.shape
+    N = b.shape[0]
+    out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        _call(_gemm_nt, _ptr(a), _ptr(b), _ptr(bias), _ptr(out), M, N, Kd, _stream(a.device))
+    return out

@@ -1,0 +1,56 @@
+"""CPU: the C-ABI library loads and exports every symbol include/pcf_hip.h declares; the Python
+`pcf_cuda` module exposes the reference's nine functions and rejects host tensors the way the
+reference's CHECK_INPUT does.  No compute calls (no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+def _declared():
+    text = open(os.path.join(ROOT, 'include', 'pcf_hip.h')).read()
+    return sorted(set(re.findall(r'\b(pcf_hip_\w+)\s*\(', text)))
+
+
+def test_header_symbols_exported():
+    import pcf_cuda
+    lib = ctypes.CDLL(pcf_cuda.library_path())
+    names = _declared()
+    assert len(names) >= 14
+    for n in names:
+        assert hasattr(lib, n), f'{n} declared in include/pcf_hip.h but not exported'
+
+
+def test_module_surface_matches_reference():
+    import pcf_cuda
+    # pcf_cuda.cpp:10-18
+    for n in ['pcf_forward', 'pcf_backward', 'pconv_forward', 'pconv_linear_forward', 'pconv_backward',
+              'pconv_linear_backward', 'pconv_linear_opt_backward', 'compute_knn_inverse',
+              'pconv_linear_cutlass_forward']:
+        assert callable(getattr(pcf_cuda, n)), n
+    assert 'gfx950' in pcf_cuda.version()
+
+
+def test_host_tensors_rejected_like_check_input():
+    import pcf_cuda
+    x = torch.zeros(1, 4, 4)
+    idx = torch.zeros(1, 4, 2, dtype=torch.long)
+    with pytest.raises(RuntimeError, match='must be a CUDA tensor'):
+        pcf_cuda.pcf_forward(x, idx, torch.zeros(1, 4, 2, 2), torch.zeros(1, 4, 2, 4))
+    with pytest.raises(RuntimeError, match='must be a CUDA tensor'):
+        pcf_cuda.compute_knn_inverse(idx, 4)
+
+
+def test_c_abi_argument_errors_without_gpu():
+    """Argument validation happens before any HIP call, so it can be exercised on CPU."""
+    import pcf_cuda
+    lib = ctypes.CDLL(pcf_cuda.library_path())
+    lib.pcf_hip_last_error.restype = ctypes.c_char_p
+    rc = lib.pcf_hip_knn(None, None, None, None, 1, 10, 65, None, None)
+    assert rc == -1 and b'K must be in [1,64]' in lib.pcf_hip_last_error()
+    lib.pcf_hip_knn_inverse_workspace_bytes.restype = ctypes.c_size_t
+    assert lib.pcf_hip_knn_inverse_workspace_bytes(1, 100, 16, 100) > 100 * 16 * 4

@@ -1,0 +1,339 @@
+"""GPU: the HIP operators (through the C ABI, via the drop-in `pcf_cuda` module) against the oracle.
+
+Bar (BASELINE.json north_star): indices bit-exact, features / gradients within 1e-3 in fp32.  The
+comparisons here use rtol = atol = 2e-4 -- tighter than the bar; what differs is summation order.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, split
+from oracle import pcf_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = dict(rtol=2e-4, atol=2e-4)
+
+
+def _mk(shape, gen, dev, scale=1.0):
+    return (torch.randn(shape, generator=gen) * scale).to(dev)
+
+
+def _case(B, N, Nout, K, Ci, Ca, Cm, H, seed, bad_frac=0.0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, N, Ci, generator=g)
+    idx = torch.randint(0, max(N, 1), (B, Nout, K), generator=g)
+    if bad_frac > 0:
+        bad = torch.rand(B, Nout, K, generator=g) < bad_frac
+        idx = torch.where(bad, torch.where(torch.rand(B, Nout, K, generator=g) < 0.5, -1, N + 3), idx)
+    guid = torch.rand(B, Nout, K, max(H, 1), generator=g)
+    w = torch.randn(B, Nout, K, Cm, generator=g)
+    add = torch.randn(B, Nout, K, Ca, generator=g)
+    return x, idx, guid, w, add
+
+
+def _safe(idx, N):
+    """oracle-side view of out-of-range neighbours: they contribute nothing."""
+    ok = (idx >= 0) & (idx < N)
+    return idx.clamp(0, max(N - 1, 0)), ok
+
+
+PCF_SHAPES = [
+    # B, N, Nout, K, Ci, Cm, H
+    (1, 500, 500, 16, 16, 16, 8),      # BASELINE layer shape (C=64 -> Ci=16)
+    (1, 300, 100, 8, 32, 4, 4),        # strided, Cm=4
+    (2, 64, 40, 5, 12, 3, 3),          # batch 2, odd K, Cm and H not powers of two (generic path)
+    (1, 200, 200, 16, 96, 16, 8),      # widest PCFLayer of configPCF_10cm
+    (1, 130, 130, 16, 48, 8, 8),
+    (1, 90, 90, 16, 64, 32, 1),
+    (1, 33, 77, 3, 7, 1, 7),           # Cm=1, odd Ci
+]
+
+
+@pytest.mark.parametrize('shape', PCF_SHAPES)
+def test_pcf_forward_backward(device, shape):
+    import pcf_cuda
+    B, N, Nout, K, Ci, Cm, H = shape
+    x, idx, guid, w, _ = _case(B, N, Nout, K, Ci, 0, Cm, H, seed=sum(shape))
+    out = pcf_cuda.pcf_forward(x.to(device), idx.to(device), guid.to(device), w.to(device))
+    want = O.pcf_forward(x, idx, guid, w)
+    torch.testing.assert_close(out.cpu(), want, **TOL)
+    gout = torch.randn(want.shape, generator=torch.Generator().manual_seed(7))
+    gx, gg, gw = pcf_cuda.pcf_backward(gout.to(device), x.to(device), idx.to(device), guid.to(device), w.to(device))
+    wx, wg, ww = O.pcf_backward(gout, x, idx, guid, w)
+    torch.testing.assert_close(gw.cpu(), ww, **TOL)
+    torch.testing.assert_close(gg.cpu(), wg, **TOL)
+    torch.testing.assert_close(gx.cpu(), wx, **TOL)
+
+
+PCONV_SHAPES = [
+    # B, N, Nout, K, Ci, Ca, Cm
+    (1, 256, 256, 16, 3, 0, 16),       # test_configs/pointconv_single.yaml layer
+    (1, 144, 144, 16, 6, 12, 16),      # level-0 PointConv of configPCF_10cm
+    (1, 240, 90, 12, 16, 16, 16),      # PointConvStridePE
+    (1, 60, 200, 16, 128, 16, 1),      # PointConvTransposePE: N < Nout, Cm=1
+    (1, 50, 120, 16, 384, 32, 1),      # widest decoder layer
+    (2, 70, 70, 4, 8, 4, 4),
+    (1, 100, 100, 16, 16, 5, 16),      # Ca not a multiple of 4 -> scalar rows
+    (1, 40, 40, 64, 16, 16, 16),       # K=64, the shape of test_kernels.py:1090-1094
+]
+
+
+@pytest.mark.parametrize('shape', PCONV_SHAPES)
+def test_pconv_forward_backward(device, shape):
+    import pcf_cuda
+    B, N, Nout, K, Ci, Ca, Cm = shape
+    x, idx, _, w, add = _case(B, N, Nout, K, Ci, Ca, Cm, 1, seed=sum(shape))
+    d = lambda t: t.to(device)
+    out = pcf_cuda.pconv_forward(d(x), d(idx), d(w), d(add))
+    want = O.pconv_forward(x, idx, w, add)
+    torch.testing.assert_close(out.cpu(), want, **TOL)
+    gout = torch.randn(want.shape, generator=torch.Generator().manual_seed(11))
+    gx, gw, ga = pcf_cuda.pconv_backward(d(gout), d(x), d(idx), d(w), d(add))
+    wx, ww, wa = O.pconv_backward(gout, x, idx, w, add)
+    torch.testing.assert_close(gw.cpu(), ww, **TOL)
+    torch.testing.assert_close(ga.cpu(), wa, **TOL)
+    torch.testing.assert_close(gx.cpu(), wx, **TOL)
+
+
+def test_out_of_range_neighbours_are_ignored(device):
+    import pcf_cuda
+    B, N, Nout, K, Ci, Ca, Cm, H = 1, 120, 80, 16, 16, 4, 16, 8
+    x, idx, guid, w, add = _case(B, N, Nout, K, Ci, Ca, Cm, H, seed=5, bad_frac=0.2)
+    sidx, ok = _safe(idx, N)
+    d = lambda t: t.to(device)
+    out = pcf_cuda.pcf_forward(d(x), d(idx), d(guid), d(w))
+    torch.testing.assert_close(out.cpu(), O.pcf_forward(x, sidx, guid * ok[..., None], w), **TOL)
+    out = pcf_cuda.pconv_forward(d(x), d(idx), d(w), d(add))
+    xz = torch.cat([x, torch.zeros(B, 1, Ci)], 1)                      # row N = zeros
+    want = O.pconv_forward(xz, torch.where(ok, idx, N), w, add)
+    torch.testing.assert_close(out.cpu(), want, **TOL)
+    gout = torch.randn(want.shape, generator=torch.Generator().manual_seed(3))
+    gx, gw, ga = pcf_cuda.pconv_backward(d(gout), d(x), d(idx), d(w), d(add))
+    wx, ww, wa = O.pconv_backward(gout, xz, torch.where(ok, idx, N), w, add)
+    torch.testing.assert_close(gx.cpu(), wx[:, :N], **TOL)
+    torch.testing.assert_close(gw.cpu(), ww, **TOL)
+    torch.testing.assert_close(ga.cpu(), wa, **TOL)
+
+
+def test_empty_inputs(device):
+    import pcf_cuda
+    z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=device)
+    out = pcf_cuda.pcf_forward(z(1, 10, 8), z(1, 0, 4, dt=torch.long), z(1, 0, 4, 2), z(1, 0, 4, 4))
+    assert out.shape == (1, 0, 32)
+    gx, gg, gw = pcf_cuda.pcf_backward(z(1, 0, 32), z(1, 10, 8), z(1, 0, 4, dt=torch.long), z(1, 0, 4, 2), z(1, 0, 4, 4))
+    assert gx.shape == (1, 10, 8) and float(gx.abs().sum()) == 0.0
+    inv_n, inv_k, inv_idx = pcf_cuda.compute_knn_inverse(z(1, 0, 4, dt=torch.long), 5)
+    assert inv_idx.cpu().tolist() == [[0] * 6] and inv_n.shape == (1, 0)
+
+
+@pytest.mark.parametrize('name,has_guid', [('pcf_self_64', True), ('pcf_self_32_64', True), ('pcf_strided', True)])
+def test_pcf_against_reference_golden(device, name, has_guid):
+    """Tensors the reference's own PCFLayer produced around its aggregate (tests/golden)."""
+    import pcf_cuda
+    g = load_golden(name)
+    d = lambda t: t.contiguous().to(device)
+    out = pcf_cuda.pcf_forward(d(g['cap.fx']), d(g['in.nei_inds']), d(g['cap.score']), d(g['cap.w']))
+    torch.testing.assert_close(out.cpu(), g['cap.agg'], **TOL)
+    gx, gg, gw = pcf_cuda.pcf_backward(d(g['gcap.agg']), d(g['cap.fx']), d(g['in.nei_inds']), d(g['cap.score']),
+                                       d(g['cap.w']))
+    torch.testing.assert_close(gg.cpu(), g['gcap.score'], **TOL)
+    torch.testing.assert_close(gw.cpu(), g['gcap.w'], **TOL)
+
+
+def test_pconv_linear_against_reference_golden(device):
+    import pcf_cuda
+    d = lambda t: t.contiguous().to(device)
+    # Ca = 0 (pointconv_single): forward, backward (atomics) and opt backward (CSR)
+    g = load_golden('pointconv_single')
+    x, idx, w = g['in.dense_feats'], g['in.nei_inds'], g['cap.w']
+    add = torch.zeros(1, idx.shape[1], idx.shape[2], 0)
+    lw, lb = g['sd.linear.weight'], g['sd.linear.bias']
+    for fwd in (pcf_cuda.pconv_linear_forward, pcf_cuda.pconv_linear_cutlass_forward):
+        out, p = fwd(d(x), d(idx), d(w), d(add), d(lw), d(lb))
+        torch.testing.assert_close(p.cpu(), g['cap.agg'], **TOL)
+        torch.testing.assert_close(out.cpu(), g['cap.lin'], **TOL)
+    want = (g['gin.dense_feats'], g['gcap.w'], None, g['gsd.linear.weight'], g['gsd.linear.bias'])
+    got = pcf_cuda.pconv_linear_backward(d(g['gcap.lin']), d(x), d(idx), d(w), d(add), d(lw), p)
+    inv = pcf_cuda.compute_knn_inverse(d(idx), x.shape[1])
+    got2 = pcf_cuda.pconv_linear_opt_backward(d(g['gcap.lin']), d(x), *inv, d(idx), d(w), d(add), d(lw), p)
+    for res in (got, got2):
+        for a, b in zip(res, want):
+            if b is not None:
+                torch.testing.assert_close(a.cpu(), b, **TOL)
+    # Ca = 16, strided (stride_pe) and Cm = 1, N < Nout (transpose_pe): aggregate part
+    for name, xk in (('stride_pe', 'cap.fx'), ('transpose_pe', 'in.sparse_feats'), ('pointconv_vi_pe', 'in.dense_feats')):
+        g = load_golden(name)
+        add = g['cap.pe'] if 'cap.pe' in g else g['out.wn_in']
+        lw = g['sd.linear.c.weight']
+        lb = g['sd.linear.c.bias']
+        out, p = pcf_cuda.pconv_linear_forward(d(g[xk]), d(g['in.nei_inds']), d(g['cap.w']), d(add), d(lw), d(lb))
+        torch.testing.assert_close(p.cpu(), g['cap.agg'], **TOL)
+        torch.testing.assert_close(out.cpu(), g['cap.lin'], **TOL)
+
+
+LIN_SHAPES = [
+    # B, N, Nout, K, Ci, Ca, Cm, Co
+    (1, 300, 300, 16, 6, 12, 16, 64),     # 288 -> 64
+    (1, 300, 120, 16, 16, 16, 16, 32),    # 512 -> 32 (narrow tile)
+    (1, 80, 250, 16, 128, 16, 1, 64),     # 144 -> 64, N < Nout
+    (2, 90, 90, 8, 8, 4, 4, 16),
+    (1, 1000, 1000, 16, 3, 0, 16, 32),    # enough points for a split-K reduction of grad_lin_w
+    (1, 64, 64, 16, 3, 0, 1, 5),          # J = 3: scalar GEMM loads
+]
+
+
+@pytest.mark.parametrize('shape', LIN_SHAPES)
+def test_pconv_linear_forward_backward(device, shape):
+    import pcf_cuda
+    B, N, Nout, K, Ci, Ca, Cm, Co = shape
+    x, idx, _, w, add = _case(B, N, Nout, K, Ci, Ca, Cm, 1, seed=sum(shape))
+    g = torch.Generator().manual_seed(99)
+    J = (Ci + Ca) * Cm
+    lw = torch.randn(Co, J, generator=g) / J ** 0.5
+    lb = torch.randn(Co, generator=g)
+    d = lambda t: t.to(device)
+    out, p = pcf_cuda.pconv_linear_forward(d(x), d(idx), d(w), d(add), d(lw), d(lb))
+    wout, wp = O.pconv_linear_forward(x, idx, w, add, lw, lb)
+    torch.testing.assert_close(p.cpu(), wp, **TOL)
+    torch.testing.assert_close(out.cpu(), wout, **TOL)
+    gout = torch.randn(wout.shape, generator=g)
+    want = O.pconv_linear_backward(gout, x, idx, w, add, lw, wp)
+    got = pcf_cuda.pconv_linear_backward(d(gout), d(x), d(idx), d(w), d(add), d(lw), p)
+    inv = pcf_cuda.compute_knn_inverse(d(idx), N)
+    got2 = pcf_cuda.pconv_linear_opt_backward(d(gout), d(x), *inv, d(idx), d(w), d(add), d(lw), p)
+    scale = max(1.0, float(want[3].abs().max()))
+    for res in (got, got2):
+        for i, (a, b) in enumerate(zip(res, want)):
+            tol = dict(rtol=2e-4, atol=2e-4 * scale) if i >= 3 else TOL
+            torch.testing.assert_close(a.cpu(), b, **tol)
+    # the CSR path is deterministic: bitwise identical across runs
+    again = pcf_cuda.pconv_linear_opt_backward(d(gout), d(x), *inv, d(idx), d(w), d(add), d(lw), p)
+    assert torch.equal(again[0], got2[0])
+
+
+def test_opt_backward_rejects_short_csr(device):
+    import pcf_cuda
+    B, N, Nout, K, Ci, Ca, Cm, Co = 1, 50, 50, 4, 4, 0, 4, 8
+    x, idx, _, w, add = _case(B, N, Nout, K, Ci, Ca, Cm, 1, seed=1)
+    d = lambda t: t.to(device)
+    lw = torch.randn(Co, 16)
+    out, p = pcf_cuda.pconv_linear_forward(d(x), d(idx), d(w), d(add), d(lw), d(torch.zeros(Co)))
+    inv_n, inv_k, inv_idx = pcf_cuda.compute_knn_inverse(d(idx), N)
+    with pytest.raises(RuntimeError, match='inverse_neighbor_idx size must be'):
+        pcf_cuda.pconv_linear_opt_backward(d(torch.zeros(1, Nout, Co)), d(x), inv_n, inv_k, inv_idx[:, :N].contiguous(),
+                                           d(idx), d(w), d(add), d(lw), p)
+    with pytest.raises(RuntimeError, match='must be contiguous'):
+        pcf_cuda.pconv_forward(d(x).transpose(1, 2).transpose(1, 2)[:, ::2], d(idx), d(w), d(add))
+
+
+@pytest.mark.parametrize('Nq,K,total,seed', [(500, 16, 500, 0), (300, 8, 1000, 1), (2000, 16, 150, 2), (77, 255, 9, 3)])
+def test_knn_inverse_bit_exact(device, Nq, K, total, seed):
+    """CSR transpose: every array identical to the oracle (buckets in (query, k) order).  The third
+    case has mean in-degree 213 (> 64: LDS sort path), the fourth 2181 per bucket at K = 255."""
+    import pcf_cuda
+    rng = np.random.default_rng(seed)
+    idx = rng.integers(0, total, (Nq, K)).astype(np.int64)
+    idx[rng.random((Nq, K)) < 0.05] = -1
+    idx[rng.random((Nq, K)) < 0.02] = total + 5
+    inv_n, inv_k, inv_idx = pcf_cuda.compute_knn_inverse(torch.from_numpy(idx)[None].to(device), total)
+    wn, wk, wi = O.knn_inverse(idx, total)
+    assert inv_n.dtype == torch.int32 and inv_k.dtype == torch.uint8 and inv_idx.dtype == torch.int32
+    np.testing.assert_array_equal(inv_idx[0].cpu().numpy(), wi)
+    np.testing.assert_array_equal(inv_n[0].cpu().numpy(), wn)
+    np.testing.assert_array_equal(inv_k[0].cpu().numpy(), wk)
+
+
+def test_knn_inverse_one_huge_bucket(device):
+    """Every edge points at the same target: 8000 entries in one bucket (rank-by-counting path)."""
+    import pcf_cuda
+    idx = np.full((500, 16), 3, np.int64)
+    inv_n, inv_k, inv_idx = pcf_cuda.compute_knn_inverse(torch.from_numpy(idx)[None].to(device), 10)
+    wn, wk, wi = O.knn_inverse(idx, 10)
+    np.testing.assert_array_equal(inv_idx[0].cpu().numpy(), wi)
+    np.testing.assert_array_equal(inv_n[0].cpu().numpy(), wn)
+    np.testing.assert_array_equal(inv_k[0].cpu().numpy(), wk)
+
+
+@pytest.mark.parametrize('K', [1, 5, 16, 24, 40])
+def test_knn_bit_exact_small(device, K):
+    import pcf_cuda
+    rng = np.random.default_rng(K)
+    ref = rng.random((900, 3), dtype=np.float32)
+    qry = rng.random((700, 3), dtype=np.float32)
+    ref[10] = ref[3]                                   # duplicate points: ties resolved by index
+    roff, qoff = [0, 300, 900], [0, 500, 700]
+    got = pcf_cuda.knn_packed(torch.from_numpy(ref).to(device), torch.from_numpy(qry).to(device),
+                              torch.tensor(roff, dtype=torch.int32, device=device),
+                              torch.tensor(qoff, dtype=torch.int32, device=device), K)
+    np.testing.assert_array_equal(got.cpu().numpy(), O.knn_packed(ref, qry, roff, qoff, K))
+
+
+def test_knn_golden_and_self_first(device):
+    import pcf_cuda
+    for tag, K in (('self', 16), ('cross', 16), ('k5', 5)):
+        g = load_golden('knn_' + tag)
+        off = lambda n: torch.tensor([0, n], dtype=torch.int32, device=device)
+        got = pcf_cuda.knn_packed(g['ref'].to(device), g['query'].to(device), off(len(g['ref'])), off(len(g['query'])), K)
+        got = got.cpu().numpy()
+        dist = g['dist'].numpy()
+        untied = np.all(np.diff(dist, axis=1) > 1e-7, axis=1)
+        np.testing.assert_array_equal(got[untied], g['idx'].numpy()[untied])
+        if tag == 'self':
+            np.testing.assert_array_equal(got[:, 0], np.arange(len(got)))   # layers.py:377-378 relies on this
+
+
+def test_knn_fewer_refs_than_k(device):
+    import pcf_cuda
+    ref = torch.rand(5, 3)
+    got = pcf_cuda.knn_packed(ref.to(device), ref.to(device), torch.tensor([0, 5], dtype=torch.int32, device=device),
+                              torch.tensor([0, 5], dtype=torch.int32, device=device), 8).cpu()
+    assert (got[:, 5:] == -1).all() and (got[:, :5] >= 0).all()
+
+
+def test_knn_bit_exact_20k(device):
+    from oracle import knn_c
+    import pcf_cuda
+    rng = np.random.default_rng(42)
+    ref = (rng.random((20000, 3), dtype=np.float32) * 4).astype(np.float32)
+    roff = [0, 7000, 20000]
+    got = pcf_cuda.knn_packed(torch.from_numpy(ref).to(device), torch.from_numpy(ref).to(device),
+                              torch.tensor(roff, dtype=torch.int32, device=device),
+                              torch.tensor(roff, dtype=torch.int32, device=device), 16)
+    np.testing.assert_array_equal(got.cpu().numpy(), knn_c.knn_packed(ref, ref, roff, roff, 16))
+
+
+def test_gemm_nt(device):
+    import pcf_cuda
+    g = torch.Generator().manual_seed(0)
+    for M, N, Kd in [(1000, 32, 256), (333, 96, 288), (64, 64, 16), (70, 5, 3), (4096, 192, 1536)]:
+        a, b, bias = torch.randn(M, Kd, generator=g), torch.randn(N, Kd, generator=g), torch.randn(N, generator=g)
+        got = pcf_cuda.gemm_nt(a.to(device), b.to(device), bias.to(device)).cpu()
+        want = (a.double() @ b.double().t() + bias.double()).float()
+        torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-4 * Kd ** 0.5)
+
+
+# ---- BASELINE size (N = 80 000, K = 16, Ci = 16, Cm = 16, H = 8): size-independent properties ----
+def test_full_size_adjoint_and_linearity(device):
+    """<gout, F(x)> == <grad_x, x>, same for w and guidance (F is linear in each), and
+    F(a*x1 + b*x2) == a F(x1) + b F(x2); N = 80k is far beyond what the CPU oracle runs in seconds."""
+    import pcf_cuda
+    N, K, Ci, Cm, H = 80000, 16, 16, 16, 8
+    g = torch.Generator(device='cpu').manual_seed(1)
+    x = torch.randn(1, N, Ci, generator=g).to(device)
+    x2 = torch.randn(1, N, Ci, generator=g).to(device)
+    idx = torch.randint(0, N, (1, N, K), generator=g).to(device)
+    guid = torch.rand(1, N, K, H, generator=g).to(device)
+    w = torch.randn(1, N, K, Cm, generator=g).to(device)
+    gout = torch.randn(1, N, Ci * Cm, generator=g).to(device)
+    out = pcf_cuda.pcf_forward(x, idx, guid, w)
+    gx, gg, gw = pcf_cuda.pcf_backward(gout, x, idx, guid, w)
+    lhs = (gout.double() * out.double()).sum()
+    for grad, arg in ((gx, x), (gg, guid), (gw, w)):
+        rhs = (grad.double() * arg.double()).sum()
+        assert abs(float(lhs - rhs)) <= 1e-5 * abs(float(lhs)) + 1e-2, (float(lhs), float(rhs))
+    mix = pcf_cuda.pcf_forward(0.5 * x - 2.0 * x2, idx, guid, w)
+    torch.testing.assert_close(mix, 0.5 * out - 2.0 * pcf_cuda.pcf_forward(x2, idx, guid, w), rtol=1e-4, atol=1e-3)
+    # spot rows against the oracle
+    rows = torch.tensor([0, 1, 39999, 79999])
+    sub = O.pcf_forward(x.cpu(), idx.cpu()[:, rows], guid.cpu()[:, rows], w.cpu()[:, rows])
+    torch.testing.assert_close(out.cpu()[:, rows], sub, **TOL)
