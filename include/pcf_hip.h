@@ -131,6 +131,29 @@ int pcf_hip_knn_inverse(const int64_t* idx, int32_t* inv_neighbors, uint8_t* inv
 int pcf_hip_knn(const float* ref, const float* query, const int32_t* ref_off, const int32_t* query_off,
                 int n_seg, int max_queries_per_seg, int K, int64_t* out, void* stream);
 
+/* ---- per-edge helpers around the aggregate ---------------------------------------------------
+ * replace index_points (layer_utils.py:13-30) and its index_put_ backward: */
+/* out[b,s,:] = table[b, idx[b,s], :]   table [B,N,C], idx [B,S] i64 (S = M*K for a neighbour table) */
+int pcf_hip_gather_rows(const float* table, const int64_t* idx, float* out, int B, int N, long long S, int C,
+                        void* stream);
+/* grad_table[b, idx[b,s], :] += grad_rows[b,s,:]  (grad_table is zeroed first; float atomics) */
+int pcf_hip_scatter_add_rows(const float* grad_rows, const int64_t* idx, float* grad_table, int B, int N,
+                             long long S, int C, void* stream);
+/* replaces torch.max(index_points(dense_feats, nei_inds), dim=2)[0] (layers.py:403-408,728-733):
+ * out[b,m,c] = max_k table[b, idx[b,m,k], c]; argk u8 [B,M,C] = first maximising k (for backward). */
+int pcf_hip_gather_max(const float* table, const int64_t* idx, float* out, uint8_t* argk, int B, int N, int M,
+                       int K, int C, void* stream);
+int pcf_hip_gather_max_backward(const float* grad_out, const int64_t* idx, const uint8_t* argk, float* grad_table,
+                                int B, int N, int M, int K, int C, void* stream);
+/* replaces index_points(xyz) - centre, index_points(normals) and VI_coordinate_transform
+ * (layers.py:337-358, layer_utils.py:176-231) in one pass:
+ * rel [B,M,K,3] = ref_xyz[idx] - ctr_xyz (nullable), vi [B,M,K,12] (nullable; needs both normals). */
+int pcf_hip_edge_geometry(const float* ref_xyz, const float* ref_norm, const int64_t* idx, const float* ctr_xyz,
+                          const float* ctr_norm, float* rel, float* vi, int B, int N, int M, int K, void* stream);
+/* VI_coordinate_transform on already-gathered tensors (layer_utils.py:176-231). */
+int pcf_hip_vi_from_gathered(const float* rel, const float* nbr_norm, const float* ctr_norm, float* vi, int B, int M,
+                             int K, void* stream);
+
 /* ---- dense fp32 contraction used by the linear stage (exposed for tests / roofline) ----------
  * C[M,N] = A[M,Kd] . B^T  (+ bias[N] if bias != NULL), B given as [N,Kd] row-major.  MFMA f32. */
 int pcf_hip_gemm_nt(const float* A, const float* Bm, const float* bias, float* C, int M, int N, int Kd,

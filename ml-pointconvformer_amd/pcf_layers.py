@@ -1,0 +1,415 @@
+"""Host-side mirror of the reference's operator boundary and of the layers that call it.
+
+Same class names, constructor arguments, ``forward`` signatures, sub-module names (so a reference
+``state_dict`` loads unchanged) and config switches (``USE_CUDA_KERNEL``, ``PCONV_OPT``, ``USE_VI``,
+``USE_PE``, ``BATCH_NORM``) as
+
+  * ``layer_utils.py``  : ``index_points`` :13-30, ``PConvLinearOpt{,Function}`` :42-86,
+                          ``PCF{,Function}`` :89-124, ``PConv{,Function}`` :127-173,
+                          ``VI_coordinate_transform`` :176-231, ``Linear_BN`` :241-277, ``UnaryBlock`` :281-319
+  * ``layers.py``       : ``MultiHeadGuidance`` :23-68, ``WeightNet`` :127-191, ``PCFLayer`` :194-416,
+                          ``PointConvStridePE`` :542-741, ``PointConv`` :744-906, ``PointConvTransposePE`` :909-1105
+
+but every neighbourhood operation goes to the HIP kernels behind ``pcf_cuda`` / ``pcf_fused``:
+this module never gathers with advanced indexing and has no PyTorch fallback for the aggregate --
+on a machine without the HIP library the import of ``pcf_cuda`` fails.  Dense per-point linears
+and BatchNorm use torch (rocBLAS / MIOpen): they are plain library calls, not the hot path.
+
+Deliberate differences from the reference:
+  * ``USE_CUDA_KERNEL`` / ``PCONV_OPT`` are honoured as *which operator entry point* is used
+    (separate aggregate + Linear_BN, or the fused aggregate+linear op); both run on HIP.
+  * WeightNet is not gradient-checkpointed (288 GB of HBM makes the recompute pointless), so BN
+    running statistics are updated once per step, not twice (SURVEY.md section 7 "hard parts").
+  * The autograd backward is the true adjoint.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+import pcf_cuda
+import pcf_fused
+
+
+# --------------------------------------------------------------------------------------------------
+# operator boundary (layer_utils.py:42-173)
+# --------------------------------------------------------------------------------------------------
+class PCFFunction(torch.autograd.Function):
+    """Guided aggregate.  (layer_utils.py:89-106)"""
+
+    @staticmethod
+    def forward(ctx, input_feat, neighbor_inds, guidance, weightnet):
+        out = pcf_cuda.pcf_forward(input_feat, neighbor_inds, guidance, weightnet)
+        ctx.save_for_backward(input_feat, neighbor_inds, guidance, weightnet)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        gi, gg, gw = pcf_cuda.pcf_backward(grad_output.contiguous(), *ctx.saved_tensors)
+        return gi, None, gg, gw
+
+
+class PCF(nn.Module):
+    """(layer_utils.py:109-124)"""
+
+    @staticmethod
+    def forward(input_features, neighbor_inds, guidance, weightnet):
+        return PCFFunction.apply(input_features, neighbor_inds, guidance, weightnet)
+
+
+class PConvFunction(torch.autograd.Function):
+    """Unguided aggregate with appended per-edge features.  (layer_utils.py:127-153)"""
+
+    @staticmethod
+    def forward(ctx, input_feat, neighbor_inds, weightnet, additional_features):
+        out = pcf_cuda.pconv_forward(input_feat, neighbor_inds, weightnet, additional_features)
+        ctx.save_for_backward(input_feat, neighbor_inds, weightnet, additional_features)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        gi, gw, ga = pcf_cuda.pconv_backward(grad_output.contiguous(), *ctx.saved_tensors)
+        return gi, None, gw, ga
+
+
+def _empty_additional(input_features, neighbor_inds):
+    # the reference builds this on the CPU (layer_utils.py:168), which its own CHECK_CUDA rejects
+    B, Nout, K = neighbor_inds.shape
+    return input_features.new_zeros(B, Nout, K, 0)
+
+
+class PConv(nn.Module):
+    """(layer_utils.py:156-173)"""
+
+    @staticmethod
+    def forward(input_features, neighbor_inds, weightnet, additional_features=None):
+        if additional_features is None:
+            additional_features = _empty_additional(input_features, neighbor_inds)
+        return PConvFunction.apply(input_features, neighbor_inds, weightnet, additional_features)
+
+
+class PConvLinearOptFunction(torch.autograd.Function):
+    """Aggregate + linear, backward over the inverse CSR.  (layer_utils.py:42-70)"""
+
+    @staticmethod
+    def forward(ctx, input_feat, neighbor_inds, inverse_neighbors, inverse_k, inverse_idx, weightnet,
+                additional_features, linear_weights, linear_bias):
+        output, pconv_output = pcf_cuda.pconv_linear_cutlass_forward(
+            input_feat, neighbor_inds, weightnet, additional_features, linear_weights, linear_bias)
+        ctx.save_for_backward(input_feat, inverse_neighbors, inverse_k, inverse_idx, neighbor_inds, weightnet,
+                              additional_features, linear_weights, pconv_output)
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        (input_feat, inverse_neighbors, inverse_k, inverse_idx, neighbor_inds, weightnet, additional_features,
+         linear_weights, pconv_output) = ctx.saved_tensors
+        g = pcf_cuda.pconv_linear_opt_backward(grad_output.contiguous(), input_feat, inverse_neighbors, inverse_k,
+                                               inverse_idx, neighbor_inds, weightnet, additional_features,
+                                               linear_weights, pconv_output)
+        return g[0], None, None, None, None, g[1], g[2], g[3], g[4]
+
+
+class PConvLinearOpt(nn.Module):
+    """(layer_utils.py:73-86)"""
+
+    def __init__(self, in_features, out_features):
+        super().__init__()
+        self.linear = nn.Linear(in_features, out_features)
+
+    def forward(self, input_features, neighbor_inds, inverse_neighbors, inverse_k, inverse_idx, weightnet,
+                additional_features=None):
+        if additional_features is None:
+            additional_features = _empty_additional(input_features, neighbor_inds)
+        if inverse_neighbors is None:      # the reference would crash; build the CSR on the fly instead
+            inverse_neighbors, inverse_k, inverse_idx = pcf_cuda.compute_knn_inverse(
+                neighbor_inds, input_features.shape[1])
+        return PConvLinearOptFunction.apply(input_features, neighbor_inds, inverse_neighbors, inverse_k, inverse_idx,
+                                            weightnet, additional_features, self.linear.weight, self.linear.bias)
+
+
+def index_points(points, idx):
+    """points [B,N,C], idx [B,S] or [B,S,K] -> [B,S,(K,)C] on the HIP row-gather (differentiable).
+    (layer_utils.py:13-30)"""
+    return pcf_fused.gather_rows(points, idx)
+
+
+def VI_coordinate_transform(localized_xyz, gathered_norm, sparse_xyz_norm, K=None):
+    """Viewpoint-invariant descriptor from already-gathered tensors (layer_utils.py:176-231).  The
+    layers below call the fused gather+transform kernel instead; this entry point exists for callers
+    that hold the gathered tensors."""
+    return pcf_fused.vi_from_gathered(localized_xyz, gathered_norm, sparse_xyz_norm)
+
+
+# --------------------------------------------------------------------------------------------------
+# Linear_BN / UnaryBlock (layer_utils.py:241-319)
+# --------------------------------------------------------------------------------------------------
+class Linear_BN(nn.Module):
+    """Linear followed by BatchNorm over every axis but the last.  ``bn_ver`` is accepted for
+    signature compatibility; both versions normalise the channel (last) axis."""
+
+    def __init__(self, in_dim, out_dim, bn_ver='2d', bn_weight_init=1, bn_momentum=0.1):
+        super().__init__()
+        self.c = nn.Linear(in_dim, out_dim)
+        self.bn_ver = bn_ver
+        self.bn = nn.BatchNorm1d(out_dim, momentum=bn_momentum)
+        nn.init.constant_(self.bn.weight, bn_weight_init)
+
+    @torch.no_grad()
+    def fuse(self):
+        """Fold the running statistics into one nn.Linear for inference.  (layer_utils.py:260-270)"""
+        s = self.bn.weight * torch.rsqrt(self.bn.running_var + self.bn.eps)
+        lin = nn.Linear(self.c.in_features, self.c.out_features).to(self.c.weight.device)
+        lin.weight.copy_(self.c.weight * s[:, None])
+        lin.bias.copy_(self.bn.bias + (self.c.bias - self.bn.running_mean) * s)
+        return lin
+
+    def forward(self, x):
+        y = self.c(x)
+        return self.bn(y.reshape(-1, y.shape[-1])).view(y.shape)
+
+
+class UnaryBlock(nn.Module):
+    def __init__(self, in_dim, out_dim, use_bn, bn_momentum, no_relu=False):
+        super().__init__()
+        self.in_dim, self.out_dim, self.use_bn, self.no_relu = in_dim, out_dim, use_bn, no_relu
+        self.mlp = Linear_BN(in_dim, out_dim, bn_momentum=bn_momentum, bn_ver='1d') if use_bn \
+            else nn.Linear(in_dim, out_dim)
+
+    def forward(self, x):
+        x = self.mlp(x)
+        return x if self.no_relu else F.leaky_relu(x, 0.1)
+
+
+# --------------------------------------------------------------------------------------------------
+# per-edge MLPs (layers.py:23-68, 127-191)
+# --------------------------------------------------------------------------------------------------
+class MultiHeadGuidance(nn.Module):
+    """sigmoid(MLP_{C -> 8 -> heads}(query - key)), ReLU between the two layers."""
+
+    def __init__(self, cfg, num_heads: int, num_hiddens: int):
+        super().__init__()
+        if getattr(cfg, 'layer_norm_guidance', False):
+            raise NotImplementedError('layer_norm_guidance=True is outside the hot path (SURVEY.md 8f-4)')
+        self.num_heads, self.dim = num_heads, num_hiddens
+        dims = [num_hiddens, 8, num_heads]
+        self.mlp = nn.ModuleList(
+            Linear_BN(a, b) if cfg.BATCH_NORM else nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
+
+    def forward(self, guidance_query, guidance_key):
+        s = guidance_query - guidance_key
+        last = len(self.mlp) - 1
+        for i, layer in enumerate(self.mlp):
+            s = layer(s)
+            s = torch.sigmoid(s) if i == last else F.relu(s)
+        return s
+
+
+class WeightNet(nn.Module):
+    """Linear_BN + ReLU after every layer, the last one included."""
+
+    def __init__(self, in_channel, out_channel, hidden_unit=(8, 8), efficient=False):
+        super().__init__()
+        dims = [in_channel] + list(hidden_unit or []) + [out_channel]
+        self.mlp_convs = nn.ModuleList(Linear_BN(a, b) for a, b in zip(dims[:-1], dims[1:]))
+        self.efficient = efficient   # accepted, unused: no checkpointing on MI355X
+
+    def forward(self, localized_xyz):
+        w = localized_xyz
+        for conv in self.mlp_convs:
+            w = F.relu(conv(w))
+        return w
+
+
+# --------------------------------------------------------------------------------------------------
+# layers
+# --------------------------------------------------------------------------------------------------
+def _edge_geometry(cfg_use_vi, ref_xyz, ref_norm, nei_inds, ctr_xyz, ctr_norm, vi_features):
+    """-> (localized_xyz or None, weightNetInput).  One fused HIP kernel gathers the neighbour
+    coordinates / normals and emits the offsets and the 12-channel VI descriptor."""
+    if cfg_use_vi and vi_features is not None:
+        return None, vi_features
+    rel, vi = pcf_fused.edge_geometry(ref_xyz, ref_norm if cfg_use_vi else None, nei_inds, ctr_xyz,
+                                      ctr_norm if cfg_use_vi else None)
+    return rel, (vi if cfg_use_vi else rel)
+
+
+def _drop_path(cfg):
+    if getattr(cfg, 'drop_path_rate', 0.) > 0.:
+        raise NotImplementedError('drop_path_rate > 0 needs timm.DropPath; every BASELINE config uses 0')
+    return nn.Identity()
+
+
+class PCFLayer(nn.Module):
+    """PointConvFormer layer.  (layers.py:194-416)"""
+
+    def __init__(self, in_channel, out_channel, cfg, weightnet=[9, 16], num_heads=4, guidance_feat_len=32):
+        super().__init__()
+        if cfg.attention_type != 'subtraction':
+            raise NotImplementedError('QK guidance is outside the hot path (SURVEY.md 8f-4)')
+        self.cfg, self.in_channel, self.out_channel, self.num_heads = cfg, in_channel, out_channel, num_heads
+        self.drop_path = _drop_path(cfg)
+        self.mlp_conv = Linear_BN(12, guidance_feat_len) if cfg.BATCH_NORM else nn.Linear(12, guidance_feat_len)
+        mid = out_channel // 4
+        self.unary1 = UnaryBlock(in_channel, mid, use_bn=True, bn_momentum=0.1) if in_channel != mid else nn.Identity()
+        self.guidance_unary = UnaryBlock(mid, guidance_feat_len, use_bn=True, bn_momentum=0.1, no_relu=True)
+        assert (out_channel // 2) % num_heads == 0
+        self.guidance_weight = MultiHeadGuidance(cfg, num_heads, 2 * guidance_feat_len)
+        self.weightnet = WeightNet(weightnet[0], weightnet[1], efficient=True)
+        self.linear = Linear_BN(mid * weightnet[-1], out_channel // 2, bn_ver='1d') if cfg.BATCH_NORM \
+            else nn.Linear(mid * weightnet[-1], out_channel // 2)
+        self.dropout = nn.Dropout(p=cfg.dropout_rate) if cfg.dropout_rate > 0. else nn.Identity()
+        self.unary2 = UnaryBlock(out_channel // 2, out_channel, use_bn=True, bn_momentum=0.1, no_relu=True)
+        self.unary_shortcut = UnaryBlock(in_channel, out_channel, use_bn=True, bn_momentum=0.1, no_relu=True) \
+            if in_channel != out_channel else nn.Identity()
+
+    def forward(self, dense_xyz, dense_feats, nei_inds, dense_xyz_norm, sparse_xyz=None, sparse_xyz_norm=None,
+                vi_features=None, inv_neighbors=None, inv_k=None, inv_idx=None):
+        strided = sparse_xyz is not None
+        ctr_xyz = sparse_xyz if strided else dense_xyz
+        ctr_norm = sparse_xyz_norm if strided else dense_xyz_norm
+        nei_inds = nei_inds.contiguous()
+        feats_x = self.unary1(dense_feats)
+        _, wn_in = _edge_geometry(self.cfg.USE_VI is True, dense_xyz, dense_xyz_norm, nei_inds, ctr_xyz, ctr_norm,
+                                  vi_features)
+        feat_pe = F.relu(self.mlp_conv(wn_in))
+        guidance_x = self.guidance_unary(feats_x)
+        # query - key, with key = neighbour 0 (self) or the max over the neighbourhood when strided
+        query = torch.cat([index_points(guidance_x, nei_inds), feat_pe], dim=-1)
+        key = query[:, :, :1] if not strided else query.max(dim=2, keepdim=True)[0]
+        guidance_score = self.guidance_weight(query, key)
+        weights = self.weightnet(wn_in)
+        agg = PCF.forward(feats_x.contiguous(), nei_inds, guidance_score.contiguous(), weights.contiguous())
+        new_feat = self.unary2(self.dropout(F.relu(self.linear(agg))))
+        sparse_feats = pcf_fused.gather_max(dense_feats, nei_inds) if strided else dense_feats
+        shortcut = self.unary_shortcut(sparse_feats)
+        return F.leaky_relu(self.drop_path(new_feat) + shortcut, 0.1), wn_in
+
+
+class _ConvTail(nn.Module):
+    """Shared tail of the PointConv family: aggregate + linear, chosen by PCONV_OPT / USE_CUDA_KERNEL."""
+
+    def _build_linear(self, cfg, in_features, out_features):
+        if cfg.PCONV_OPT:
+            self.pconv_linear_opt = PConvLinearOpt(in_features, out_features)
+            if cfg.BATCH_NORM:
+                self.bn = nn.BatchNorm1d(out_features, momentum=0.1)
+        else:
+            self.linear = Linear_BN(in_features, out_features, bn_ver='1d') if cfg.BATCH_NORM \
+                else nn.Linear(in_features, out_features)
+
+    def _aggregate_linear(self, feats, nei_inds, weights, additional, inv_neighbors, inv_k, inv_idx):
+        feats, weights = feats.contiguous(), weights.contiguous()
+        additional = None if additional is None else additional.contiguous()
+        if self.cfg.PCONV_OPT:
+            y = self.pconv_linear_opt(feats, nei_inds, inv_neighbors, inv_k, inv_idx, weights, additional)
+            if self.cfg.BATCH_NORM:
+                y = self.bn(y.reshape(-1, y.shape[-1])).view(y.shape)
+            return y
+        return self.linear(PConv.forward(feats, nei_inds, weights, additional))
+
+
+class PointConvStridePE(_ConvTail):
+    """PointConv with a learned positional embedding appended to the gathered features.  (layers.py:542-741)"""
+
+    def __init__(self, in_channel, out_channel, cfg, weightnet=[9, 16]):
+        super().__init__()
+        self.cfg, self.in_channel, self.out_channel = cfg, in_channel, out_channel
+        self.drop_path = _drop_path(cfg)
+        mid = out_channel // 4
+        last_ch = min(mid, 32)
+        self.pe_convs = WeightNet(3, last_ch, hidden_unit=[mid], efficient=True)
+        self.unary1 = UnaryBlock(in_channel, mid, use_bn=True, bn_momentum=0.1) if in_channel != mid else nn.Identity()
+        self.weightnet = WeightNet(weightnet[0], weightnet[1], efficient=True)
+        self._build_linear(cfg, (mid + last_ch) * weightnet[-1], out_channel // 2)
+        self.dropout = nn.Dropout(p=cfg.dropout_rate) if cfg.dropout_rate > 0. else nn.Identity()
+        self.unary2 = UnaryBlock(out_channel // 2, out_channel, use_bn=True, bn_momentum=0.1, no_relu=True)
+        self.unary_shortcut = UnaryBlock(in_channel, out_channel, use_bn=True, bn_momentum=0.1, no_relu=True) \
+            if in_channel != out_channel else nn.Identity()
+
+    def forward(self, dense_xyz, dense_feats, nei_inds, dense_xyz_norm, sparse_xyz=None, sparse_xyz_norm=None,
+                vi_features=None, inv_neighbors=None, inv_k=None, inv_idx=None):
+        strided = sparse_xyz is not None
+        ctr_xyz = sparse_xyz if strided else dense_xyz
+        ctr_norm = sparse_xyz_norm if strided else dense_xyz_norm
+        nei_inds = nei_inds.contiguous()
+        feats_x = self.unary1(dense_feats)
+        rel, wn_in = _edge_geometry(self.cfg.USE_VI is True, dense_xyz, dense_xyz_norm, nei_inds, ctr_xyz, ctr_norm,
+                                    vi_features)
+        if rel is None:                       # VI features were handed in: offsets still needed for the PE
+            rel, _ = pcf_fused.edge_geometry(dense_xyz, None, nei_inds, ctr_xyz, None)
+        feat_pe = self.pe_convs(rel)
+        weights = self.weightnet(wn_in)
+        y = F.relu(self._aggregate_linear(feats_x, nei_inds, weights, feat_pe, inv_neighbors, inv_k, inv_idx))
+        y = self.unary2(self.dropout(y))
+        sparse_feats = pcf_fused.gather_max(dense_feats, nei_inds) if strided else dense_feats
+        shortcut = self.unary_shortcut(sparse_feats)
+        return F.leaky_relu(self.drop_path(y) + shortcut, 0.1), wn_in
+
+
+class PointConv(_ConvTail):
+    """First-layer (VI_)PointConv without bottleneck.  (layers.py:744-906)"""
+
+    def __init__(self, in_channel, out_channel, cfg, weightnet=[9, 16], USE_VI=None):
+        super().__init__()
+        self.cfg, self.in_channel, self.out_channel = cfg, in_channel, out_channel
+        self.USE_VI = cfg.USE_VI if USE_VI is None else USE_VI
+        last_ch = in_channel + ((12 if self.USE_VI else 3) if cfg.USE_PE else 0)
+        self.weightnet = WeightNet(weightnet[0], weightnet[1], efficient=True)
+        self._build_linear(cfg, last_ch * weightnet[-1], out_channel)
+        self.dropout = nn.Dropout(p=cfg.dropout_rate) if cfg.dropout_rate > 0. else nn.Identity()
+
+    def forward(self, dense_xyz, dense_feats, nei_inds, dense_xyz_norm=None, sparse_xyz=None, sparse_xyz_norm=None,
+                inv_neighbors=None, inv_k=None, inv_idx=None):
+        strided = sparse_xyz is not None
+        nei_inds = nei_inds.contiguous()
+        _, wn_in = _edge_geometry(self.USE_VI is True, dense_xyz, dense_xyz_norm, nei_inds,
+                                  sparse_xyz if strided else dense_xyz,
+                                  sparse_xyz_norm if strided else dense_xyz_norm, None)
+        weights = self.weightnet(wn_in)
+        additional = wn_in if self.cfg.USE_PE else None
+        y = self._aggregate_linear(dense_feats, nei_inds, weights, additional, inv_neighbors, inv_k, inv_idx)
+        return self.dropout(F.relu(y)), wn_in
+
+
+class PointConvTransposePE(_ConvTail):
+    """Upsampling PointConv: features move from the sparse level to the dense one.  (layers.py:909-1105)"""
+
+    def __init__(self, in_channel, out_channel, cfg, weightnet=[9, 16], mlp2=None):
+        super().__init__()
+        self.cfg, self.in_channel, self.out_channel = cfg, in_channel, out_channel
+        self.drop_path = _drop_path(cfg)
+        if cfg.USE_PE:
+            last_ch = min(out_channel // 4, 32)
+            self.pe_convs = WeightNet(3, last_ch, hidden_unit=[out_channel // 4], efficient=True)
+        else:
+            last_ch = 0
+            self.pe_convs = nn.ModuleList()
+        self.weightnet = WeightNet(weightnet[0], weightnet[1], efficient=True)
+        self._build_linear(cfg, (last_ch + in_channel) * weightnet[-1], out_channel)
+        self.dropout = nn.Dropout(p=cfg.dropout_rate) if cfg.dropout_rate > 0. else nn.Identity()
+        self.mlp2_convs = nn.ModuleList()
+        self.mlp2_bns = nn.ModuleList()
+        if mlp2 is not None:
+            for a, b in zip(mlp2[:-1], mlp2[1:]):
+                self.mlp2_convs.append(Linear_BN(a, b, bn_ver='1d') if cfg.BATCH_NORM else nn.Linear(a, b))
+
+    def forward(self, sparse_xyz, sparse_feats, nei_inds, sparse_xyz_norm, dense_xyz, dense_xyz_norm, dense_feats=None,
+                vi_features=None, inv_neighbors=None, inv_k=None, inv_idx=None):
+        nei_inds = nei_inds.contiguous()
+        rel, wn_in = _edge_geometry(self.cfg.USE_VI is True, sparse_xyz, sparse_xyz_norm, nei_inds, dense_xyz,
+                                    dense_xyz_norm, vi_features)
+        feat_pe = None
+        if self.cfg.USE_PE:
+            if rel is None:
+                rel, _ = pcf_fused.edge_geometry(sparse_xyz, None, nei_inds, dense_xyz, None)
+            feat_pe = self.pe_convs(rel)
+        weights = self.weightnet(wn_in)
+        y = F.relu(self._aggregate_linear(sparse_feats, nei_inds, weights, feat_pe, inv_neighbors, inv_k, inv_idx))
+        if dense_feats is not None:
+            y = y + dense_feats
+        y = self.dropout(y)
+        for conv in self.mlp2_convs:
+            y = F.relu(conv(y))
+        return y, wn_in

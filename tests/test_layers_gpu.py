@@ -1,0 +1,181 @@
+"""GPU: the host-side layer mirror (pcf_layers, HIP kernels underneath) against the golden vectors
+the REFERENCE layers produced (outputs, input gradients, every parameter gradient), and against the
+oracle on a second seed.  fp32, tolerance 1e-3 as BASELINE.json states; tighter where possible."""
+import pytest
+import torch
+
+from conftest import load_golden, split
+
+pytestmark = pytest.mark.gpu
+TOL = dict(rtol=1e-3, atol=1e-3)
+
+
+class Cfg(dict):
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+
+def cfg(**kw):
+    c = Cfg(attention_type='subtraction', BATCH_NORM=True, drop_path_rate=0., dropout_rate=0., USE_VI=True,
+            USE_PE=False, PCONV_OPT=False, USE_CUDA_KERNEL=True, layer_norm_guidance=False)
+    c.update(kw)
+    return c
+
+
+def _remap_for_pconv_opt(sd):
+    """PCONV_OPT=True stores the same tensors under other names (layers.py:591-602)."""
+    out = {}
+    for k, v in sd.items():
+        k = k.replace('linear.c.', 'pconv_linear_opt.linear.') if k.startswith('linear.c.') else k
+        k = k.replace('linear.bn.', 'bn.') if k.startswith('linear.bn.') else k
+        if k in ('linear.weight', 'linear.bias'):
+            k = 'pconv_linear_opt.' + k
+        out[k] = v
+    return out
+
+
+def _unmap(name):
+    if name.startswith('pconv_linear_opt.linear.'):
+        return [name.replace('pconv_linear_opt.linear.', 'linear.c.'), name.replace('pconv_linear_opt.', '')]
+    if name.startswith('bn.'):
+        return ['linear.' + name]
+    return [name]
+
+
+def _run(layer, g, device, feat_keys, order, opt=False):
+    sd = split(g, 'sd.')
+    layer.load_state_dict(_remap_for_pconv_opt(sd) if opt else sd, strict=True)
+    layer.to(device).train()
+    a = split(g, 'in.')
+    args = {}
+    for k in order:
+        v = a.get(k)
+        if v is None:
+            args[k] = None
+            continue
+        v = v.to(device)
+        if k in feat_keys:
+            v.requires_grad_(True)
+        args[k] = v
+    out, wn = layer(**args)
+    torch.testing.assert_close(wn.cpu(), g['out.wn_in'], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(out.cpu(), g['out.new_feat'], **TOL)
+    out.backward(g['gup'].to(device))
+    for k in feat_keys:
+        torch.testing.assert_close(args[k].grad.cpu(), g['gin.' + k], **TOL)
+    want = split(g, 'gsd.')
+    seen = 0
+    for name, p in layer.named_parameters():
+        keys = [k for k in _unmap(name) if k in want] if opt else [name]
+        assert keys and p.grad is not None, name
+        ref = want[keys[0]]
+        tol = TOL
+        if name.endswith('c.bias') or (opt and name == 'pconv_linear_opt.linear.bias' and 'bn.weight' in dict(layer.named_parameters())):
+            tol = dict(rtol=0, atol=5e-3)     # analytically zero gradient in front of a batch-stat BN
+        torch.testing.assert_close(p.grad.cpu(), ref, **tol, msg=lambda m, n=name: f'{n}: {m}')
+        seen += 1
+    assert seen == len(want)
+    return layer
+
+
+PCF_ORDER = ['dense_xyz', 'dense_feats', 'nei_inds', 'dense_xyz_norm', 'sparse_xyz', 'sparse_xyz_norm']
+
+
+@pytest.mark.parametrize('name,ci,co,cm,heads', [('pcf_self_64', 64, 64, 16, 8), ('pcf_self_32_64', 32, 64, 16, 8),
+                                                 ('pcf_strided', 32, 64, 4, 4)])
+def test_pcf_layer_matches_reference(device, name, ci, co, cm, heads):
+    import pcf_layers
+    g = load_golden(name)
+    layer = pcf_layers.PCFLayer(ci, co, cfg(), weightnet=[12, cm], num_heads=heads, guidance_feat_len=32)
+    _run(layer, g, device, ['dense_feats'], PCF_ORDER)
+
+
+@pytest.mark.parametrize('opt', [False, True])
+def test_pointconv_single_matches_reference(device, opt):
+    import pcf_layers
+    g = load_golden('pointconv_single')
+    c = cfg(BATCH_NORM=False, USE_PE=False, USE_VI=False, PCONV_OPT=opt)
+    layer = pcf_layers.PointConv(3, 32, c, weightnet=[3, 16])
+    _run(layer, g, device, ['dense_feats'], ['dense_xyz', 'dense_feats', 'nei_inds'], opt=opt)
+
+
+@pytest.mark.parametrize('opt', [False, True])
+def test_pointconv_vi_pe_matches_reference(device, opt):
+    import pcf_layers
+    g = load_golden('pointconv_vi_pe')
+    layer = pcf_layers.PointConv(6, 64, cfg(USE_PE=True, PCONV_OPT=opt), weightnet=[12, 16])
+    _run(layer, g, device, ['dense_feats'], ['dense_xyz', 'dense_feats', 'nei_inds', 'dense_xyz_norm'], opt=opt)
+
+
+@pytest.mark.parametrize('opt', [False, True])
+def test_stride_pe_matches_reference(device, opt):
+    import pcf_layers
+    g = load_golden('stride_pe')
+    layer = pcf_layers.PointConvStridePE(64, 64, cfg(USE_PE=True, PCONV_OPT=opt), weightnet=[12, 16])
+    _run(layer, g, device, ['dense_feats'], PCF_ORDER, opt=opt)
+
+
+@pytest.mark.parametrize('opt', [False, True])
+def test_transpose_pe_matches_reference(device, opt):
+    import pcf_layers
+    g = load_golden('transpose_pe')
+    layer = pcf_layers.PointConvTransposePE(128, 64, cfg(USE_PE=True, PCONV_OPT=opt), weightnet=[12, 1], mlp2=[64, 64])
+    _run(layer, g, device, ['sparse_feats', 'dense_feats'],
+         ['sparse_xyz', 'sparse_feats', 'nei_inds', 'sparse_xyz_norm', 'dense_xyz', 'dense_xyz_norm', 'dense_feats'], opt=opt)
+
+
+def test_edge_geometry_and_gathers_against_oracle(device):
+    import pcf_fused
+    from oracle import pcf_oracle as O
+    g = torch.Generator().manual_seed(3)
+    B, N, M, K, C = 2, 150, 60, 7, 20
+    xyz, nrm = torch.rand(B, N, 3, generator=g), torch.nn.functional.normalize(torch.randn(B, N, 3, generator=g), dim=-1)
+    cxyz, cnrm = torch.rand(B, M, 3, generator=g), torch.nn.functional.normalize(torch.randn(B, M, 3, generator=g), dim=-1)
+    idx = torch.randint(0, N, (B, M, K), generator=g)
+    d = lambda t: t.to(device)
+    rel, vi = pcf_fused.edge_geometry(d(xyz), d(nrm), d(idx), d(cxyz), d(cnrm))
+    wrel = O.gather_rows(xyz, idx) - cxyz.unsqueeze(2)
+    torch.testing.assert_close(rel.cpu(), wrel, rtol=0, atol=0)
+    torch.testing.assert_close(vi.cpu(), O.vi_features(wrel, O.gather_rows(nrm, idx), cnrm), rtol=1e-4, atol=1e-5)
+    vi2 = pcf_fused.vi_from_gathered(rel, d(O.gather_rows(nrm, idx)), d(cnrm))
+    torch.testing.assert_close(vi2, vi, rtol=0, atol=0)
+    # reference golden for the VI transform, zero offsets (self edges) included
+    gg = load_golden('vi_transform')
+    _, vig = pcf_fused.edge_geometry(d(gg['xyz'][None]), d(gg['nrm'][None]), d(gg['idx'][None]), d(gg['xyz'][None]),
+                                     d(gg['nrm'][None]))
+    torch.testing.assert_close(vig[0].cpu(), gg['vi'], rtol=1e-4, atol=1e-5)
+    # differentiable gathers
+    t = torch.randn(B, N, C, generator=g)
+    td = d(t).requires_grad_(True)
+    got = pcf_fused.gather_rows(td, d(idx))
+    torch.testing.assert_close(got.cpu(), O.gather_rows(t, idx), rtol=0, atol=0)
+    up = torch.randn(got.shape, generator=g)
+    got.backward(d(up))
+    tr = t.clone().requires_grad_(True)
+    O.gather_rows(tr, idx).backward(up)
+    torch.testing.assert_close(td.grad.cpu(), tr.grad, rtol=1e-5, atol=1e-5)
+    td.grad = None
+    mx = pcf_fused.gather_max(td, d(idx))
+    want = O.gather_rows(tr, idx).max(2)[0]
+    torch.testing.assert_close(mx.cpu(), want, rtol=0, atol=0)
+    up = torch.randn(mx.shape, generator=g)
+    mx.backward(d(up))
+    tr.grad = None
+    want.backward(up)
+    torch.testing.assert_close(td.grad.cpu(), tr.grad, rtol=1e-5, atol=1e-5)
+
+
+def test_linear_bn_fuse(device):
+    """Inference-time folding of BN into the linear (layer_utils.py:260-270)."""
+    import pcf_layers
+    torch.manual_seed(0)
+    m = pcf_layers.Linear_BN(12, 8).to(device)
+    x = torch.randn(2, 50, 16, 12, device=device)
+    m.train()
+    for _ in range(3):
+        m(x)
+    m.eval()
+    torch.testing.assert_close(m.fuse()(x), m(x), rtol=1e-4, atol=1e-5)
