@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py -- PCFLayer forward+backward throughput on MI355X (BASELINE.json's headline metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload: ``PCFLayer(in=64, out=64, weightnet=[12,16],
+num_heads=8, guidance_feat_len=32)`` with ``USE_VI=True, BATCH_NORM=True``, train mode, one packed
+cloud of N = 80 000 points per GPU, K = 16 self-neighbours; a step is one forward plus
+``out.sum().backward()``.  Inputs are synthetic (seed 1: xyz ~ U[0,1)^3, unit normals, features
+~ N(0,1)), resident in HBM before the timed region; the kNN that builds the neighbour table is
+excluded from the step and reported separately (``knn_ms``).  With N > 1 GPUs every rank runs its own
+cloud (the per-scene operator does not shard) under DistributedDataParallel: the only
+collective is the gradient all-reduce over RCCL.  value = points processed by all ranks / wall time.
+
+Also reported on the one JSON line: ``roofline`` for the dominant hand-written kernel (HIP events
+around its launches inside the timed region) and ``cpu_baseline`` (the oracle's CPU restatement of the
+same layer, timed on this host; rank 0, 1 GPU only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'ml-pointconvformer_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch
+import torch.distributed as dist
+
+N_POINTS, K_NEI, C_FEAT, HEADS, C_MID, GUID = 80000, 16, 64, 8, 16, 32
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+
+# Algorithmic HBM bytes per point of the aggregate operator, fp32 + int64 indices.
+def _agg_bytes(Ci, Cm, H, K):
+    fwd = 4 * K * Ci + 8 * K + 4 * K * H + 4 * K * Cm + 4 * Ci * Cm
+    bwd = (4 * Ci * Cm + 4 * K * Ci + 8 * K + 4 * K * H + 4 * K * Cm) + (4 * K * Cm + 4 * K * H + 4 * K * Ci)
+    return fwd, bwd
+
+
+class Cfg(dict):
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+
+def layer_cfg():
+    return Cfg(attention_type='subtraction', BATCH_NORM=True, drop_path_rate=0., dropout_rate=0., USE_VI=True,
+               USE_PE=True, PCONV_OPT=True, USE_CUDA_KERNEL=True, layer_norm_guidance=False)
+
+
+def synth_cloud(n, seed):
+    g = torch.Generator().manual_seed(seed)
+    xyz = torch.rand(1, n, 3, generator=g)
+    nrm = torch.nn.functional.normalize(torch.randn(1, n, 3, generator=g), dim=-1)
+    feats = torch.randn(1, n, C_FEAT, generator=g)
+    return xyz, nrm, feats
+
+
+def cpu_baseline(state_dict, xyz, nrm, feats, idx, iters=3):
+    """The oracle's restatement of PCFLayer fwd+bwd on the host cores (kind = "port")."""
+    from oracle import pcf_oracle as O
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    torch.set_num_threads(max(1, cores))
+    sd = {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point() and 'running' not in k)
+          for k, v in state_dict.items()}
+    P = O.Params(sd, '', True)
+    f = feats.cpu().clone().requires_grad_(True)
+    x, n, i = xyz.cpu(), nrm.cpu(), idx.cpu()
+
+    def step():
+        out, _ = O.pcf_layer(P, x, f, i, n, num_heads=HEADS)
+        out.sum().backward()
+        for v in sd.values():
+            v.grad = None
+        f.grad = None
+
+    step()
+    ts = []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        step()
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    med = ts[len(ts) // 2]
+    return {'value': round(xyz.shape[1] / med, 1), 'unit': 'points/s', 'cores': torch.get_num_threads(),
+            'kind': 'port', 'sample': f'full workload N={xyz.shape[1]} K={idx.shape[2]}, 1 warm-up + {iters} timed '
+            f'iterations, median {med * 1e3:.0f} ms; oracle/pcf_oracle.py:pcf_layer on torch CPU'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--points', type=int, default=N_POINTS)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit('bench.py: launch N>1 with torch.distributed.run (one process per GPU)')
+        args.gpus = world
+    assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback for the HIP path)'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    import pcf_cuda
+    import pcf_layers
+
+    torch.manual_seed(1)
+    layer = pcf_layers.PCFLayer(C_FEAT, C_FEAT, layer_cfg(), weightnet=[12, C_MID], num_heads=HEADS,
+                                guidance_feat_len=GUID).to(dev).train()
+    model = layer
+    if world > 1:
+        model = torch.nn.parallel.DistributedDataParallel(layer, device_ids=[local_rank])
+
+    n = args.points
+    xyz, nrm, feats = synth_cloud(n, seed=1 + rank)
+    xyz, nrm, feats = xyz.to(dev), nrm.to(dev), feats.to(dev).requires_grad_(True)
+    off = torch.tensor([0, n], dtype=torch.int32, device=dev)
+    pcf_cuda.knn_packed(xyz[0], xyz[0], off, off, K_NEI)           # warm the kernel
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    idx = pcf_cuda.knn_packed(xyz[0], xyz[0], off, off, K_NEI)[None].contiguous()
+    torch.cuda.synchronize()
+    knn_ms = (time.perf_counter() - t0) * 1e3
+
+    def step():
+        out, _ = model(xyz, feats, idx, nrm)
+        out.sum().backward()
+        for p in layer.parameters():
+            p.grad = None
+        feats.grad = None
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    timeline = pcf_cuda.record_kernel_times(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    pcf_cuda.record_kernel_times(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-entry-point device time inside the timed region (events on the launch stream)
+    per = {}
+    for name, e0, e1 in timeline:
+        per.setdefault(name, []).append(e0.elapsed_time(e1))
+    hip_ms = {k: sum(v) / len(v) for k, v in per.items()}
+    hip_total_ms = sum(sum(v) for v in per.values()) / max(args.steps, 1)
+
+    if rank == 0:
+        Ci = C_FEAT // 4
+        fwd_b, bwd_b = _agg_bytes(Ci, C_MID, HEADS, K_NEI)
+        cand = {'pcf_hip_pcf_forward': (fwd_b, 'agg_fwd_kernel<16,true>'),
+                'pcf_hip_pcf_backward': (bwd_b, 'agg_bwd_kernel<16,true,true>')}
+        dom = max((k for k in cand if k in hip_ms), key=lambda k: hip_ms[k])
+        bytes_per_launch = cand[dom][0] * n
+        achieved = bytes_per_launch / (hip_ms[dom] * 1e-3) / 1e9
+        roofline = {'bound': 'hbm', 'kernel': cand[dom][1], 'entry_point': dom,
+                    'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+                    'algorithmic_bytes_per_launch': bytes_per_launch,
+                    'avg_launch_ms': round(hip_ms[dom], 4)}
+        ms_per_step = elapsed / args.steps * 1e3
+        line = {
+            'metric': 'PCFLayer fwd+bwd points/sec (N=80k,K=16,C=64)',
+            'value': round(world * n * args.steps / elapsed, 1), 'unit': 'points/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'PCFLayer(64->64, heads 8, C_mid 16, VI+BN, train) fwd+bwd, one packed cloud '
+                                   f'N={n} K={K_NEI} per GPU (BASELINE configs[1]-class layer; metric shape)',
+                       'points_per_gpu': n, 'K': K_NEI, 'C': C_FEAT, 'parallelism': f'dp{world}'},
+            'roofline': roofline,
+            'hip_ms_per_call': {k: round(v, 4) for k, v in sorted(hip_ms.items())},
+            'hip_ms_per_step': round(hip_total_ms, 4),
+            'knn_ms': round(knn_ms, 3),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(layer.state_dict(), xyz, nrm, feats.detach(), idx)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -51,6 +51,7 @@ def _sig(name, argtypes, restype=_I):
     fn = getattr(_lib, name)
     fn.argtypes = argtypes
     fn.restype = restype
+    fn.__name__ = name
     return fn
 
 
@@ -104,8 +105,28 @@ def _stream(dev):
     return torch.cuda.current_stream(dev).cuda_stream
 
 
+_timeline = None   # when a list: (entry point name, start event, end event) per C-ABI call
+
+
+def record_kernel_times(enable: bool):
+    """Bracket every C-ABI call with HIP events on the stream it is enqueued on (torch's current
+    stream); returns the list being filled, or None when disabled.  Used by bench.py to measure the
+    dominant kernel live inside the timed region."""
+    global _timeline
+    _timeline = [] if enable else None
+    return _timeline
+
+
 def _call(fn, *args):
-    rc = fn(*args)
+    if _timeline is None:
+        rc = fn(*args)
+    else:
+        t0 = torch.cuda.Event(enable_timing=True)
+        t1 = torch.cuda.Event(enable_timing=True)
+        t0.record()
+        rc = fn(*args)
+        t1.record()
+        _timeline.append((fn.__name__, t0, t1))
     if rc != 0:
         raise RuntimeError(f'pcf_cuda: {_last_error().decode()} (code {rc})')
 

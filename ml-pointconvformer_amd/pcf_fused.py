@@ -8,7 +8,11 @@ import ctypes
 import torch
 
 import pcf_cuda
-from pcf_cuda import _P, _I, _call, _check_input, _floats, _lib, _ptr, _stream
+from pcf_cuda import _P, _I, _check_input, _floats, _lib, _ptr, _stream
+
+
+def _call(fn, *args):
+    return pcf_cuda._call(fn, *args)
 
 _LL = ctypes.c_longlong
 
@@ -17,6 +21,7 @@ def _sig(name, argtypes):
     fn = getattr(_lib, name)
     fn.argtypes = argtypes
     fn.restype = _I
+    fn.__name__ = name
     return fn
 
 
