@@ -154,6 +154,39 @@ int pcf_hip_edge_geometry(const float* ref_xyz, const float* ref_norm, const int
 int pcf_hip_vi_from_gathered(const float* rel, const float* nbr_norm, const float* ctr_norm, float* vi, int B, int M,
                              int K, void* stream);
 
+/* ---- per-edge MLP layer: y = act(BN(x . W^T + b)) over R rows, Cin, Cout <= 64 ----------------
+ * replaces Linear_BN.forward on [B,M,K,C] tensors (layer_utils.py:241-277 with
+ * util/cp_batchnorm.py:9-30) plus the activation after it in WeightNet (layers.py:163-171),
+ * MultiHeadGuidance (layers.py:47-68) and PCFLayer.mlp_conv (layers.py:361-362), and its autograd.
+ * act: 0 none, 1 ReLU, 2 LeakyReLU(0.1), 3 sigmoid.  mean == NULL means "no BatchNorm".
+ * Workspace: pcf_hip_rowlin_workspace_bytes(Cin, Cout), 16-byte aligned, scratch. */
+size_t pcf_hip_rowlin_workspace_bytes(int Cin, int Cout);
+/* Batch statistics of z = x.W^T + b (biased variance): mean_out, rstd_out = 1/sqrt(var+eps) [Cout];
+ * running_mean / running_var (nullable) are updated with `momentum` (unbiased variance), as
+ * F.batch_norm does in training mode. */
+int pcf_hip_rowlin_bn_stats(const float* x, long long R, int Cin, const float* W, const float* b, int Cout, float eps,
+                            float momentum, float* running_mean, float* running_var, float* mean_out,
+                            float* rstd_out, void* workspace, size_t workspace_bytes, void* stream);
+int pcf_hip_rowlin_forward(const float* x, long long R, int Cin, const float* W, const float* b, int Cout,
+                           const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
+                           float* y, void* stream);
+/* dy [R,Cout] -> dx [R,Cin] (nullable: skipped), dW [Cout,Cin], db [Cout], dgamma / dbeta [Cout].
+ * batch_stats != 0: BN used the statistics of this batch (training); 0: fixed statistics. */
+int pcf_hip_rowlin_backward(const float* x, const float* dy, long long R, int Cin, const float* W, const float* b,
+                            int Cout, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                            int batch_stats, int act, float* dx, float* dW, float* db, float* dgamma, float* dbeta,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- guidance difference (query - key) --------------------------------------------------------
+ * replaces layers.py:372-381 + layers.py:52-53: q = cat(index_points(guidance_x, nei), feat_pe),
+ * key = q[:, :, :1] (self) or q.max(dim=2) (strided, use_max != 0), s = q - key.
+ * gx [B,N,G], idx [B,M,K], pe [B,M,K,P] -> s [B,M,K,G+P]; argk u8 [B,M,G+P] = key index (max only). */
+int pcf_hip_guidance_diff_forward(const float* gx, const int64_t* idx, const float* pe, float* s, uint8_t* argk, int B,
+                                  int N, int M, int K, int G, int P, int use_max, void* stream);
+/* ds [B,M,K,G+P] -> dgx [B,N,G] (zeroed, float atomics), dpe [B,M,K,P]; argk NULL = key was k = 0. */
+int pcf_hip_guidance_diff_backward(const float* ds, const int64_t* idx, const uint8_t* argk, float* dgx, float* dpe,
+                                   int B, int N, int M, int K, int G, int P, void* stream);
+
 /* ---- dense fp32 contraction used by the linear stage (exposed for tests / roofline) ----------
  * C[M,N] = A[M,Kd] . B^T  (+ bias[N] if bias != NULL), B given as [N,Kd] row-major.  MFMA f32. */
 int pcf_hip_gemm_nt(const float* A, const float* Bm, const float* bias, float* C, int M, int N, int Kd,

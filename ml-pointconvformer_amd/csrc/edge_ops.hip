@@ -168,6 +168,64 @@ __global__ __launch_bounds__(BLOCK) void vi_from_gathered_kernel(const float* __
     }
 }
 
+
+// ---- guidance difference: s[pt,k,:] = q[pt,k,:] - key[pt,:],  q = [ gx[idx[pt,k]] | pe[pt,k] ] ------
+// key = q[pt,0,:] (self neighbourhoods: neighbour 0 is the point itself) or max_k q[pt,k,:] (strided).
+// Replaces the cat / slice-or-max / repeat / subtract of layers.py:372-381 and layers.py:52-53, which
+// materialise three [B,M,K,2G] tensors.  One lane per (point, channel).
+__global__ __launch_bounds__(BLOCK) void guidance_diff_fwd_kernel(const float* __restrict__ gx,
+                                                                  const int64_t* __restrict__ idx,
+                                                                  const float* __restrict__ pe, float* __restrict__ s,
+                                                                  uint8_t* __restrict__ argk, int N, int M, int K, int G,
+                                                                  int P, int use_max, long long units) {
+    const int C = G + P;
+    for (long long u = (long long)blockIdx.x * BLOCK + threadIdx.x; u < units; u += (long long)gridDim.x * BLOCK) {
+        const long long pt = u / C;
+        const int c = (int)(u - pt * C);
+        const long long b = pt / M;
+        auto q = [&](int k) -> float {
+            if (c < G) {
+                const int64_t j = idx[pt * K + k];
+                return (j >= 0 && j < N) ? gx[((size_t)(b * N + j)) * G + c] : 0.f;
+            }
+            return pe[((size_t)pt * K + k) * P + (c - G)];
+        };
+        float key = q(0);
+        int bk = 0;
+        if (use_max)
+            for (int k = 1; k < K; ++k) { const float v = q(k); if (v > key) { key = v; bk = k; } }
+        if (argk) argk[u] = (uint8_t)bk;
+        for (int k = 0; k < K; ++k) s[((size_t)pt * K + k) * C + c] = q(k) - key;
+    }
+}
+
+// dq[pt,k,c] = ds[pt,k,c] - [k == key index] * sum_k' ds[pt,k',c];  gathered part scattered into dgx.
+__global__ __launch_bounds__(BLOCK) void guidance_diff_bwd_kernel(const float* __restrict__ ds,
+                                                                  const int64_t* __restrict__ idx,
+                                                                  const uint8_t* __restrict__ argk, float* __restrict__ dgx,
+                                                                  float* __restrict__ dpe, int N, int M, int K, int G, int P,
+                                                                  long long units) {
+    const int C = G + P;
+    for (long long u = (long long)blockIdx.x * BLOCK + threadIdx.x; u < units; u += (long long)gridDim.x * BLOCK) {
+        const long long pt = u / C;
+        const int c = (int)(u - pt * C);
+        const long long b = pt / M;
+        float tot = 0.f;
+        for (int k = 0; k < K; ++k) tot += ds[((size_t)pt * K + k) * C + c];
+        const int kk = argk ? (int)argk[u] : 0;
+        for (int k = 0; k < K; ++k) {
+            float d = ds[((size_t)pt * K + k) * C + c];
+            if (k == kk) d -= tot;
+            if (c < G) {
+                const int64_t j = idx[pt * K + k];
+                if (j >= 0 && j < N) atomicAdd(dgx + ((size_t)(b * N + j)) * G + c, d);
+            } else {
+                dpe[((size_t)pt * K + k) * P + (c - G)] = d;
+            }
+        }
+    }
+}
+
 static int grid_for(long long units) { return (int)std::max<long long>(1, std::min<long long>((units + BLOCK - 1) / BLOCK, 256 * 16)); }
 
 }  // namespace pcf
@@ -259,6 +317,37 @@ int pcf_hip_vi_from_gathered(const float* rel, const float* nbr_norm, const floa
     hipLaunchKernelGGL(vi_from_gathered_kernel, dim3(grid_for(edges)), dim3(BLOCK), 0, (hipStream_t)stream, rel, nbr_norm,
                        ctr_norm, vi, K, edges, aligned16(vi));
     return check_launch("vi_from_gathered");
+}
+
+int pcf_hip_guidance_diff_forward(const float* gx, const int64_t* idx, const float* pe, float* s, uint8_t* argk, int B,
+                                  int N, int M, int K, int G, int P, int use_max, void* stream) {
+    using namespace pcf;
+    PCF_REQUIRE(B >= 0 && N >= 0 && M >= 0 && K >= 1 && K <= 255 && G >= 0 && P >= 0 && G + P >= 1, "guidance_diff: bad size");
+    const long long units = (long long)B * M * (G + P);
+    if (units == 0) return ok();
+    PCF_REQUIRE(idx && s && (G == 0 || gx) && (P == 0 || pe), "guidance_diff: null pointer");
+    PCF_REQUIRE(!use_max || argk, "guidance_diff: max key needs the argmax output");
+    hipLaunchKernelGGL(guidance_diff_fwd_kernel, dim3(grid_for(units)), dim3(BLOCK), 0, (hipStream_t)stream, gx, idx, pe, s,
+                       argk, N, M, K, G, P, use_max, units);
+    return check_launch("guidance_diff forward");
+}
+
+int pcf_hip_guidance_diff_backward(const float* ds, const int64_t* idx, const uint8_t* argk, float* dgx, float* dpe, int B,
+                                   int N, int M, int K, int G, int P, void* stream) {
+    using namespace pcf;
+    PCF_REQUIRE(B >= 0 && N >= 0 && M >= 0 && K >= 1 && K <= 255 && G >= 0 && P >= 0 && G + P >= 1, "guidance_diff_backward: bad size");
+    hipStream_t st = (hipStream_t)stream;
+    if ((size_t)B * N * G) {
+        PCF_REQUIRE(dgx, "guidance_diff_backward: dgx is null");
+        hipError_t e = hipMemsetAsync(dgx, 0, (size_t)B * N * G * 4, st);
+        if (e != hipSuccess) return fail(PCF_E_LAUNCH, "guidance_diff_backward: memset: %s", hipGetErrorString(e));
+    }
+    const long long units = (long long)B * M * (G + P);
+    if (units == 0) return ok();
+    PCF_REQUIRE(ds && idx && (P == 0 || dpe), "guidance_diff_backward: null pointer");
+    hipLaunchKernelGGL(guidance_diff_bwd_kernel, dim3(grid_for(units)), dim3(BLOCK), 0, st, ds, idx, argk, dgx, dpe, N, M, K,
+                       G, P, units);
+    return check_launch("guidance_diff backward");
 }
 
 }  // extern "C"

@@ -127,3 +127,130 @@ def vi_from_gathered(localized_xyz, gathered_norm, ctr_norm):
         _call(_vi_from_gathered, _ptr(localized_xyz), _ptr(gathered_norm), _ptr(ctr_norm), _ptr(vi), B, M, K,
               _stream(vi.device))
     return vi
+
+
+# --------------------------------------------------------------------------------------------------
+# per-edge MLP layer: y = act(BN(x W^T + b))   (csrc/edge_mlp.hip)
+# --------------------------------------------------------------------------------------------------
+ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2, 3
+ROWLIN_MAX_CHANNELS = 64
+_Z = ctypes.c_size_t
+_F = ctypes.c_float
+
+_rowlin_ws = getattr(_lib, 'pcf_hip_rowlin_workspace_bytes')
+_rowlin_ws.argtypes = [_I, _I]
+_rowlin_ws.restype = _Z
+_rowlin_stats = _sig('pcf_hip_rowlin_bn_stats', [_P, _LL, _I, _P, _P, _I, _F, _F, _P, _P, _P, _P, _P, _Z, _P])
+_rowlin_fwd = _sig('pcf_hip_rowlin_forward', [_P, _LL, _I, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P])
+_rowlin_bwd = _sig('pcf_hip_rowlin_backward', [_P, _P, _LL, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I,
+                                               _P, _P, _P, _P, _P, _P, _Z, _P])
+_gdiff_fwd = _sig('pcf_hip_guidance_diff_forward', [_P] * 5 + [_I] * 7 + [_P])
+_gdiff_bwd = _sig('pcf_hip_guidance_diff_backward', [_P] * 5 + [_I] * 6 + [_P])
+
+
+def rowlin_supported(cin, cout):
+    return 1 <= cin <= ROWLIN_MAX_CHANNELS and 1 <= cout <= ROWLIN_MAX_CHANNELS
+
+
+class _LinearBNAct(torch.autograd.Function):
+    """x [..., Cin] -> act(BN(x W^T + b)) [..., Cout]; BN over every axis but the last (batch
+    statistics when `training`, running statistics otherwise; gamma None = no BN)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, gamma, beta, running_mean, running_var, eps, momentum, training, act):
+        x = x.contiguous()
+        W, b = W.contiguous(), b.contiguous()
+        Cout, Cin = W.shape
+        R = x.numel() // Cin
+        dev = x.device
+        bn = gamma is not None
+        mean = rstd = None
+        stream = _stream(dev)
+        with torch.cuda.device(dev):
+            if bn:
+                if training:
+                    mean = torch.empty(Cout, dtype=torch.float32, device=dev)
+                    rstd = torch.empty(Cout, dtype=torch.float32, device=dev)
+                    nbytes = _rowlin_ws(Cin, Cout)
+                    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                    _call(_rowlin_stats, _ptr(x), R, Cin, _ptr(W), _ptr(b), Cout, float(eps), float(momentum),
+                          _ptr(running_mean), _ptr(running_var), _ptr(mean), _ptr(rstd), ws.data_ptr(), nbytes, stream)
+                else:
+                    mean = running_mean
+                    rstd = torch.rsqrt(running_var + eps)
+            y = torch.empty(*x.shape[:-1], Cout, dtype=torch.float32, device=dev)
+            _call(_rowlin_fwd, _ptr(x), R, Cin, _ptr(W), _ptr(b), Cout, _ptr(mean), _ptr(rstd),
+                  _ptr(gamma) if bn else None, _ptr(beta) if bn else None, int(act), _ptr(y), stream)
+        ctx.save_for_backward(x, W, b, gamma, beta, mean, rstd)
+        ctx.cfg = (bool(training), int(act), bn)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W, b, gamma, beta, mean, rstd = ctx.saved_tensors
+        training, act, bn = ctx.cfg
+        dy = dy.contiguous()
+        Cout, Cin = W.shape
+        R = x.numel() // Cin
+        dev = x.device
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dW = torch.empty_like(W)
+        db = torch.empty_like(b)
+        dgamma = torch.empty_like(gamma) if bn else None
+        dbeta = torch.empty_like(beta) if bn else None
+        nbytes = _rowlin_ws(Cin, Cout)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _call(_rowlin_bwd, _ptr(x), _ptr(dy), R, Cin, _ptr(W), _ptr(b), Cout, _ptr(mean), _ptr(rstd),
+                  _ptr(gamma) if bn else None, _ptr(beta) if bn else None, 1 if training else 0, act,
+                  _ptr(dx), _ptr(dW), _ptr(db), _ptr(dgamma), _ptr(dbeta), ws.data_ptr(), nbytes, _stream(dev))
+        return dx, dW, db, dgamma, dbeta, None, None, None, None, None, None
+
+
+def linear_bn_act(x, weight, bias, bn, act, training):
+    """Fused Linear (+BatchNorm1d module `bn`, or None) (+activation) on the last axis of x."""
+    _floats(x=x, weight=weight, bias=bias)
+    if x.shape[-1] != weight.shape[1]:
+        raise RuntimeError(f'linear_bn_act: input has {x.shape[-1]} channels, weight expects {weight.shape[1]}')
+    if bn is None:
+        return _LinearBNAct.apply(x, weight, bias, None, None, None, None, 0.0, 0.0, False, act)
+    use_batch = training or bn.running_mean is None
+    if training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    momentum = 0.1 if bn.momentum is None else bn.momentum
+    return _LinearBNAct.apply(x, weight, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, momentum,
+                              use_batch, act)
+
+
+class _GuidanceDiff(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gx, idx, pe, use_max):
+        B, N, G = gx.shape
+        _, M, K, P = pe.shape
+        dev = gx.device
+        s = torch.empty(B, M, K, G + P, dtype=torch.float32, device=dev)
+        argk = torch.empty(B, M, G + P, dtype=torch.uint8, device=dev) if use_max else None
+        with torch.cuda.device(dev):
+            _call(_gdiff_fwd, _ptr(gx), _ptr(idx), _ptr(pe), _ptr(s), _ptr(argk), B, N, M, K, G, P, 1 if use_max else 0,
+                  _stream(dev))
+        ctx.save_for_backward(idx, argk)
+        ctx.dims = (B, N, M, K, G, P)
+        return s
+
+    @staticmethod
+    def backward(ctx, ds):
+        idx, argk = ctx.saved_tensors
+        B, N, M, K, G, P = ctx.dims
+        ds = ds.contiguous()
+        dgx = torch.empty(B, N, G, dtype=torch.float32, device=ds.device)
+        dpe = torch.empty(B, M, K, P, dtype=torch.float32, device=ds.device)
+        with torch.cuda.device(ds.device):
+            _call(_gdiff_bwd, _ptr(ds), _ptr(idx), _ptr(argk), _ptr(dgx), _ptr(dpe), B, N, M, K, G, P, _stream(ds.device))
+        return dgx, None, dpe, None
+
+
+def guidance_diff(guidance_x, nei_inds, feat_pe, use_max):
+    """cat(gather(guidance_x), feat_pe) - key, key = neighbour 0 or the max over K (layers.py:372-381)."""
+    _floats(guidance_x=guidance_x, feat_pe=feat_pe)
+    _check_input(nei_inds, 'nei_inds', torch.int64)
+    return _GuidanceDiff.apply(guidance_x, nei_inds, feat_pe, bool(use_max))

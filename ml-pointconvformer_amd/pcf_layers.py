@@ -165,9 +165,32 @@ class Linear_BN(nn.Module):
         lin.bias.copy_(self.bn.bias + (self.c.bias - self.bn.running_mean) * s)
         return lin
 
-    def forward(self, x):
-        y = self.c(x)
-        return self.bn(y.reshape(-1, y.shape[-1])).view(y.shape)
+    def forward(self, x, act=pcf_fused.ACT_NONE):
+        """BN(x W^T + b), optionally followed by `act` (a pcf_fused.ACT_* code) in the same kernel."""
+        if pcf_fused.rowlin_supported(self.c.in_features, self.c.out_features):
+            return pcf_fused.linear_bn_act(x, self.c.weight, self.c.bias, self.bn, act, self.training)
+        y = self.c(x)                      # wide point-level layers: library GEMM + BatchNorm
+        y = self.bn(y.reshape(-1, y.shape[-1])).view(y.shape)
+        return _apply_act(y, act)
+
+
+def _apply_act(y, act):
+    if act == pcf_fused.ACT_RELU:
+        return F.relu(y)
+    if act == pcf_fused.ACT_LEAKY:
+        return F.leaky_relu(y, 0.1)
+    if act == pcf_fused.ACT_SIGMOID:
+        return torch.sigmoid(y)
+    return y
+
+
+def _linear_act(layer, x, act):
+    """Linear_BN or plain nn.Linear (cfg.BATCH_NORM False) followed by `act`, fused when narrow."""
+    if isinstance(layer, Linear_BN):
+        return layer(x, act)
+    if pcf_fused.rowlin_supported(layer.in_features, layer.out_features):
+        return pcf_fused.linear_bn_act(x, layer.weight, layer.bias, None, act, layer.training)
+    return _apply_act(layer(x), act)
 
 
 class UnaryBlock(nn.Module):
@@ -178,8 +201,7 @@ class UnaryBlock(nn.Module):
             else nn.Linear(in_dim, out_dim)
 
     def forward(self, x):
-        x = self.mlp(x)
-        return x if self.no_relu else F.leaky_relu(x, 0.1)
+        return _linear_act(self.mlp, x, pcf_fused.ACT_NONE if self.no_relu else pcf_fused.ACT_LEAKY)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -198,11 +220,13 @@ class MultiHeadGuidance(nn.Module):
             Linear_BN(a, b) if cfg.BATCH_NORM else nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
 
     def forward(self, guidance_query, guidance_key):
-        s = guidance_query - guidance_key
+        return self.forward_diff(guidance_query - guidance_key)
+
+    def forward_diff(self, s):
+        """Scores from the already-formed difference query - key."""
         last = len(self.mlp) - 1
         for i, layer in enumerate(self.mlp):
-            s = layer(s)
-            s = torch.sigmoid(s) if i == last else F.relu(s)
+            s = _linear_act(layer, s, pcf_fused.ACT_SIGMOID if i == last else pcf_fused.ACT_RELU)
         return s
 
 
@@ -218,7 +242,7 @@ class WeightNet(nn.Module):
     def forward(self, localized_xyz):
         w = localized_xyz
         for conv in self.mlp_convs:
-            w = F.relu(conv(w))
+            w = conv(w, pcf_fused.ACT_RELU)
         return w
 
 
@@ -273,15 +297,14 @@ class PCFLayer(nn.Module):
         feats_x = self.unary1(dense_feats)
         _, wn_in = _edge_geometry(self.cfg.USE_VI is True, dense_xyz, dense_xyz_norm, nei_inds, ctr_xyz, ctr_norm,
                                   vi_features)
-        feat_pe = F.relu(self.mlp_conv(wn_in))
+        feat_pe = _linear_act(self.mlp_conv, wn_in, pcf_fused.ACT_RELU)
         guidance_x = self.guidance_unary(feats_x)
-        # query - key, with key = neighbour 0 (self) or the max over the neighbourhood when strided
-        query = torch.cat([index_points(guidance_x, nei_inds), feat_pe], dim=-1)
-        key = query[:, :, :1] if not strided else query.max(dim=2, keepdim=True)[0]
-        guidance_score = self.guidance_weight(query, key)
+        # query - key in one kernel: key = neighbour 0 (self) or the max over the neighbourhood (strided)
+        diff = pcf_fused.guidance_diff(guidance_x.contiguous(), nei_inds, feat_pe, use_max=strided)
+        guidance_score = self.guidance_weight.forward_diff(diff)
         weights = self.weightnet(wn_in)
         agg = PCF.forward(feats_x.contiguous(), nei_inds, guidance_score.contiguous(), weights.contiguous())
-        new_feat = self.unary2(self.dropout(F.relu(self.linear(agg))))
+        new_feat = self.unary2(self.dropout(_linear_act(self.linear, agg, pcf_fused.ACT_RELU)))
         sparse_feats = pcf_fused.gather_max(dense_feats, nei_inds) if strided else dense_feats
         shortcut = self.unary_shortcut(sparse_feats)
         return F.leaky_relu(self.drop_path(new_feat) + shortcut, 0.1), wn_in
@@ -411,5 +434,5 @@ class PointConvTransposePE(_ConvTail):
             y = y + dense_feats
         y = self.dropout(y)
         for conv in self.mlp2_convs:
-            y = F.relu(conv(y))
+            y = _linear_act(conv, y, pcf_fused.ACT_RELU)
         return y, wn_in

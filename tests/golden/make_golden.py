@@ -78,8 +78,35 @@ def _save(name, blobs):
     print(f'{name}: {os.path.getsize(path) / 1024:.0f} KiB, {len(flat)} arrays')
 
 
+KINK_MARGIN = 1e-4
+
+
 def _run_layer(name, layer, args, captures, gen, meta):
-    """args: ordered dict of forward kwargs (tensors or None); captures: {tag: (module, 'in'|'out')}."""
+    """args: ordered dict of forward kwargs (tensors or None); captures: {tag: (module, 'in'|'out')}.
+
+    The gradient of a ReLU is discontinuous at 0: a fixture whose LAST pre-activation (the captured
+    ``lin`` tensor, when there is one) has an element within fp32 noise of 0 would make gradient parity
+    a coin toss for any implementation that sums in a different order.  Such a draw is rejected: the
+    feature tensor is redrawn until every element of ``lin`` is at least KINK_MARGIN away from 0."""
+    if 'lin' in captures:
+        mod, which = captures['lin']
+        feat_key = next(k for k in args if k.endswith('feats'))
+        for attempt in range(50):
+            seen = {}
+            h = mod.register_forward_hook(lambda m, i, o: seen.__setitem__('lin', o))
+            layer.train()
+            state = {k: v.clone() for k, v in layer.state_dict().items()}
+            with torch.no_grad():
+                layer(**args)
+            layer.load_state_dict(state)          # undo the running-stat update of the probe
+            h.remove()
+            if float(seen['lin'].abs().min()) >= KINK_MARGIN:
+                break
+            args[feat_key] = torch.randn(args[feat_key].shape, generator=gen)
+        else:
+            raise RuntimeError(f'{name}: no kink-free draw found')
+        if attempt:
+            print(f'{name}: redrew features {attempt}x to stay {KINK_MARGIN} away from the last ReLU kink')
     layer.train()
     sd = {k: v.clone() for k, v in layer.state_dict().items()}
     caps = {}

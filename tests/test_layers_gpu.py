@@ -179,3 +179,89 @@ def test_linear_bn_fuse(device):
         m(x)
     m.eval()
     torch.testing.assert_close(m.fuse()(x), m(x), rtol=1e-4, atol=1e-5)
+
+
+ROWLIN_CASES = [
+    # R-shape, Cin, Cout, act, bn, training
+    ((2, 300, 16), 12, 32, 1, True, True),
+    ((1, 500, 16), 64, 8, 1, True, True),
+    ((1, 400, 16), 8, 8, 3, True, True),
+    ((1, 200, 7), 8, 16, 1, True, True),
+    ((1, 777), 64, 16, 2, True, True),
+    ((1, 1000), 16, 32, 0, True, True),
+    ((1, 100, 16), 3, 16, 1, True, True),
+    ((1, 90, 16), 16, 16, 1, True, False),        # running statistics
+    ((1, 50, 16), 64, 8, 1, False, True),         # no BN (cfg.BATCH_NORM False)
+    ((1, 64, 12), 48, 32, 1, True, True),
+    ((1, 33, 5), 5, 1, 1, True, True),            # odd sizes: scalar row access, Cout = 1 (mid_dim_back)
+    ((1, 120, 16), 64, 64, 2, True, True),
+]
+
+
+@pytest.mark.parametrize('shape,cin,cout,act,bn,training', ROWLIN_CASES)
+def test_linear_bn_act_against_torch(device, shape, cin, cout, act, bn, training):
+    """Fused Linear+BatchNorm+activation (csrc/edge_mlp.hip) vs the same three torch modules on CPU
+    in fp64: output, input gradient, every parameter gradient and the running statistics."""
+    import pcf_fused
+    g = torch.Generator().manual_seed(cin * 100 + cout)
+    x = torch.randn(*shape, cin, generator=g) + 0.3
+    lin = torch.nn.Linear(cin, cout)
+    bnm = torch.nn.BatchNorm1d(cout) if bn else None
+    if bn:
+        with torch.no_grad():
+            bnm.weight.copy_(torch.rand(cout, generator=g) + 0.5)
+            bnm.bias.copy_(torch.randn(cout, generator=g) * 0.2)
+            bnm.running_mean.copy_(torch.randn(cout, generator=g) * 0.1)
+            bnm.running_var.copy_(torch.rand(cout, generator=g) + 0.5)
+    import copy
+    lin_d, bn_d = copy.deepcopy(lin).to(device), (copy.deepcopy(bnm).to(device) if bn else None)
+    ref_lin, ref_bn = copy.deepcopy(lin).double(), (copy.deepcopy(bnm).double() if bn else None)
+    for m in (bn_d, ref_bn):
+        if m is not None:
+            m.train(training)
+    actf = {0: lambda t: t, 1: torch.relu, 2: lambda t: torch.nn.functional.leaky_relu(t, 0.1), 3: torch.sigmoid}[act]
+    xr = x.double().requires_grad_(True)
+    z = ref_lin(xr)
+    if bn:
+        z = ref_bn(z.reshape(-1, cout)).view(z.shape)
+    want = actf(z)
+    up = torch.randn(want.shape, generator=g)
+    want.backward(up.double())
+    xd = x.to(device).requires_grad_(True)
+    got = pcf_fused.linear_bn_act(xd, lin_d.weight, lin_d.bias, bn_d, act, training)
+    got.backward(up.to(device))
+    tol = dict(rtol=2e-4, atol=2e-4)
+    torch.testing.assert_close(got.cpu(), want.float(), **tol)
+    torch.testing.assert_close(xd.grad.cpu(), xr.grad.float(), **tol)
+    gscale = max(1.0, float(ref_lin.weight.grad.abs().max()))
+    torch.testing.assert_close(lin_d.weight.grad.cpu(), ref_lin.weight.grad.float(), rtol=2e-4, atol=2e-4 * gscale)
+    torch.testing.assert_close(lin_d.bias.grad.cpu(), ref_lin.bias.grad.float(), rtol=2e-4, atol=2e-3 * gscale)
+    if bn:
+        torch.testing.assert_close(bn_d.weight.grad.cpu(), ref_bn.weight.grad.float(), rtol=2e-4, atol=2e-4 * gscale)
+        torch.testing.assert_close(bn_d.bias.grad.cpu(), ref_bn.bias.grad.float(), rtol=2e-4, atol=2e-4 * gscale)
+        torch.testing.assert_close(bn_d.running_mean.cpu(), ref_bn.running_mean.float(), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(bn_d.running_var.cpu(), ref_bn.running_var.float(), rtol=1e-5, atol=1e-6)
+        assert int(bn_d.num_batches_tracked) == int(ref_bn.num_batches_tracked)
+
+
+@pytest.mark.parametrize('use_max', [False, True])
+def test_guidance_diff_against_torch(device, use_max):
+    import pcf_fused
+    from oracle import pcf_oracle as O
+    g = torch.Generator().manual_seed(5)
+    B, N, M, K, G, P = 2, 90, 40, 6, 32, 32
+    gx = torch.randn(B, N, G, generator=g)
+    pe = torch.randn(B, M, K, P, generator=g)
+    idx = torch.randint(0, N, (B, M, K), generator=g)
+    gr, pr = gx.clone().requires_grad_(True), pe.clone().requires_grad_(True)
+    q = torch.cat([O.gather_rows(gr, idx), pr], -1)
+    key = q.max(2, keepdim=True)[0] if use_max else q[:, :, :1]
+    want = q - key
+    up = torch.randn(want.shape, generator=g)
+    want.backward(up)
+    gd, pd = gx.to(device).requires_grad_(True), pe.to(device).requires_grad_(True)
+    got = pcf_fused.guidance_diff(gd, idx.to(device), pd, use_max)
+    got.backward(up.to(device))
+    torch.testing.assert_close(got.cpu(), want, rtol=0, atol=0)
+    torch.testing.assert_close(pd.grad.cpu(), pr.grad, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(gd.grad.cpu(), gr.grad, rtol=1e-5, atol=1e-5)
