@@ -175,17 +175,41 @@ __global__ __launch_bounds__(BLOCK) void rowlin_stats_kernel(const RowLin a) {
     write_block_partials(s1, s2, red, a.part);
 }
 
-// ---- K2: statistics -> mean, rstd, running-stat update --------------------------------------------
-__global__ __launch_bounds__(128) void bn_stats_finalize_kernel(const float* __restrict__ part, int nblocks, long long R,
-                                                                 int Cout, float eps, float momentum,
-                                                                 float* __restrict__ running_mean,
-                                                                 float* __restrict__ running_var,
-                                                                 float* __restrict__ mean_out, float* __restrict__ rstd_out) {
-    __shared__ double s[128];
-    const int t = threadIdx.x;
+// Sum part[p][t] over p for the 128 statistics slots: 1024 threads = 8 slices x 128 slots, four
+// independent accumulators per thread so the loads pipeline, then an LDS combine in fp64.
+__device__ __forceinline__ double reduce_partials_128(const float* __restrict__ part, int nblocks, double* sh) {
+    const int t = threadIdx.x & 127, slice = threadIdx.x >> 7;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int p = slice;
+    for (; p + 24 < nblocks; p += 32) {
+        a0 += (double)part[(size_t)p * 128 + t];
+        a1 += (double)part[(size_t)(p + 8) * 128 + t];
+        a2 += (double)part[(size_t)(p + 16) * 128 + t];
+        a3 += (double)part[(size_t)(p + 24) * 128 + t];
+    }
+    for (; p < nblocks; p += 8) a0 += (double)part[(size_t)p * 128 + t];
+    sh[threadIdx.x] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
     double acc = 0.0;
-    for (int p = 0; p < nblocks; ++p) acc += (double)part[(size_t)p * 128 + t];
-    s[t] = acc;
+    if (threadIdx.x < 128) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) acc += sh[s * 128 + threadIdx.x];
+    }
+    __syncthreads();
+    return acc;
+}
+
+// ---- K2: statistics -> mean, rstd, running-stat update --------------------------------------------
+__global__ __launch_bounds__(1024) void bn_stats_finalize_kernel(const float* __restrict__ part, int nblocks, long long R,
+                                                                  int Cout, float eps, float momentum,
+                                                                  float* __restrict__ running_mean,
+                                                                  float* __restrict__ running_var,
+                                                                  float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+    __shared__ double sh[1024];
+    __shared__ double s[128];
+    const double acc = reduce_partials_128(part, nblocks, sh);
+    const int t = threadIdx.x;
+    if (t < 128) s[t] = acc;
     __syncthreads();
     if (t < Cout) {
         const double n = (double)R;
@@ -319,15 +343,15 @@ __global__ __launch_bounds__(BLOCK) void rowlin_bwd_reduce_kernel(const RowLin a
 }
 
 // ---- K5: reductions -> dgamma, dbeta, m1, m2 ------------------------------------------------------
-__global__ __launch_bounds__(128) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblocks, long long R,
-                                                               int Cout, float* __restrict__ dgamma,
-                                                               float* __restrict__ dbeta, float* __restrict__ m1,
-                                                               float* __restrict__ m2) {
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblocks, long long R,
+                                                                int Cout, float* __restrict__ dgamma,
+                                                                float* __restrict__ dbeta, float* __restrict__ m1,
+                                                                float* __restrict__ m2) {
+    __shared__ double sh[1024];
+    const double acc = reduce_partials_128(part, nblocks, sh);
     const int t = threadIdx.x;
-    double acc = 0.0;
-    for (int p = 0; p < nblocks; ++p) acc += (double)part[(size_t)p * 128 + t];
     const int o = t & 63;
-    if (o < Cout) {
+    if (t < 128 && o < Cout) {
         if (t < 64) { dbeta[o] = (float)acc; m1[o] = (float)(acc / (double)R); }
         else { dgamma[o] = (float)acc; m2[o] = (float)(acc / (double)R); }
     }
@@ -474,18 +498,38 @@ __global__ __launch_bounds__(BLOCK) void rowlin_bwd_apply_kernel(const RowLin a)
 }
 
 // ---- K7: sum the per-workgroup partials -> dW [Cout, Cin], db [Cout] ------------------------------
+// 64 outputs per workgroup x 4 slices of the partial list; consecutive lanes read consecutive
+// addresses of one partial, eight loads in flight per lane.
 __global__ __launch_bounds__(BLOCK) void rowlin_param_reduce_kernel(const float* __restrict__ part, int nblocks, int PW,
                                                                     int Cin, int Cout, float* __restrict__ dW,
                                                                     float* __restrict__ db) {
+    __shared__ float sh[BLOCK];
     const int total = Cout * Cin + Cout;
     const int stride = 64 * PW + 64;
-    for (int u = blockIdx.x * BLOCK + threadIdx.x; u < total; u += gridDim.x * BLOCK) {
+    const int u = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int slice = threadIdx.x >> 6;
+    float acc = 0.f;
+    if (u < total) {
         int src;
         if (u < Cout * Cin) { const int o = u / Cin, i = u - o * Cin; src = o * PW + i; }
         else src = 64 * PW + (u - Cout * Cin);
-        float acc = 0.f;
-        for (int p = 0; p < nblocks; ++p) acc += part[(size_t)p * stride + src];
-        if (u < Cout * Cin) dW[u] = acc; else db[u - Cout * Cin] = acc;
+        const float* q = part + src;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int p = slice;
+        for (; p + 12 < nblocks; p += 16) {
+            a0 += q[(size_t)p * stride];
+            a1 += q[(size_t)(p + 4) * stride];
+            a2 += q[(size_t)(p + 8) * stride];
+            a3 += q[(size_t)(p + 12) * stride];
+        }
+        for (; p < nblocks; p += 4) a0 += q[(size_t)p * stride];
+        acc = (a0 + a1) + (a2 + a3);
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < 64 && u < total) {
+        const float v = (sh[threadIdx.x] + sh[64 + threadIdx.x]) + (sh[128 + threadIdx.x] + sh[192 + threadIdx.x]);
+        if (u < Cout * Cin) dW[u] = v; else db[u - Cout * Cin] = v;
     }
 }
 
@@ -572,7 +616,7 @@ int pcf_hip_rowlin_bn_stats(const float* x, long long R, int Cin, const float* W
     int rc = PCF_OK;
     PCF_CIN_SWITCH(CT, rc = launch_rowlin(rowlin_stats_kernel<C>, a, grid, lds_stats(C), s, "per-edge linear: BN statistics"));
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(1), dim3(128), 0, s, a.part, grid, R, Cout, eps, momentum,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(1), dim3(1024), 0, s, a.part, grid, R, Cout, eps, momentum,
                        running_mean, running_var, mean_out, rstd_out);
     return check_launch("per-edge linear: BN finalize");
 }
@@ -634,14 +678,14 @@ int pcf_hip_rowlin_backward(const float* x, const float* dy, long long R, int Ci
         PCF_CIN_SWITCH(CT, rc = launch_rowlin(rowlin_bwd_reduce_kernel<C>, a, grid, lds_stats(C), s,
                                               "per-edge linear: BN backward reductions"));
         if (rc) return rc;
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(128), 0, s, part, grid, R, Cout, dgamma, dbeta, m1, m2);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(1024), 0, s, part, grid, R, Cout, dgamma, dbeta, m1, m2);
         if (int e = check_launch("per-edge linear: BN backward finalize")) return e;
         a.m1 = m1; a.m2 = m2;
     }
     PCF_CIN_SWITCH(CT, rc = launch_rowlin(rowlin_bwd_apply_kernel<C>, a, grid, lds_apply(C), s, "per-edge linear backward"));
     if (rc) return rc;
     const int PW = ((CT + 15) / 16) * 16;
-    hipLaunchKernelGGL(rowlin_param_reduce_kernel, dim3(ceil_div(Cout * Cin + Cout, BLOCK)), dim3(BLOCK), 0, s, part, grid,
+    hipLaunchKernelGGL(rowlin_param_reduce_kernel, dim3(ceil_div(Cout * Cin + Cout, 64)), dim3(BLOCK), 0, s, part, grid,
                        PW, Cin, Cout, dW, db);
     return check_launch("per-edge linear: parameter-gradient reduction");
 }
