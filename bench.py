@@ -106,19 +106,14 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
-    rank = int(os.environ.get('RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
-    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    import pcf_dist
+    rank, world, local_rank = pcf_dist.env_rank()
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit('bench.py: launch N>1 with torch.distributed.run (one process per GPU)')
         args.gpus = world
     assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback for the HIP path)'
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    rank, world, local_rank, dev = pcf_dist.setup('nccl')
 
     import pcf_cuda
     import pcf_layers
@@ -126,12 +121,10 @@ def main():
     torch.manual_seed(1)
     layer = pcf_layers.PCFLayer(C_FEAT, C_FEAT, layer_cfg(), weightnet=[12, C_MID], num_heads=HEADS,
                                 guidance_feat_len=GUID).to(dev).train()
-    model = layer
-    if world > 1:
-        model = torch.nn.parallel.DistributedDataParallel(layer, device_ids=[local_rank])
+    model = pcf_dist.wrap_ddp(layer, dev)
 
     n = args.points
-    xyz, nrm, feats = synth_cloud(n, seed=1 + rank)
+    xyz, nrm, feats = synth_cloud(n, seed=pcf_dist.data_seed(1, rank))
     xyz, nrm, feats = xyz.to(dev), nrm.to(dev), feats.to(dev).requires_grad_(True)
     off = torch.tensor([0, n], dtype=torch.int32, device=dev)
     pcf_cuda.knn_packed(xyz[0], xyz[0], off, off, K_NEI)           # warm the kernel
@@ -151,11 +144,7 @@ def main():
     for _ in range(args.warmup):
         step()
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    fence = lambda: pcf_dist.fence(dev)
 
     timeline = pcf_cuda.record_kernel_times(True)
     fence()
@@ -165,10 +154,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     pcf_cuda.record_kernel_times(False)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = pcf_dist.max_over_ranks(elapsed, dev)
 
     # per-entry-point device time inside the timed region (events on the launch stream)
     per = {}
@@ -193,7 +179,7 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         line = {
             'metric': 'PCFLayer fwd+bwd points/sec (N=80k,K=16,C=64)',
-            'value': round(world * n * args.steps / elapsed, 1), 'unit': 'points/s',
+            'value': round(pcf_dist.whole_job_rate(n, args.steps, world, elapsed), 1), 'unit': 'points/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'PCFLayer(64->64, heads 8, C_mid 16, VI+BN, train) fwd+bwd, one packed cloud '
@@ -207,8 +193,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(layer.state_dict(), xyz, nrm, feats.detach(), idx)
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    pcf_dist.shutdown()
 
 
 if __name__ == '__main__':

@@ -1,0 +1,75 @@
+"""One-process-per-GPU plumbing for the data-parallel runs (bench.py, training scripts).
+
+The PointConvFormer operator does not shard inside a scene: every rank owns whole
+packed clouds and the only data-path collective is the gradient all-reduce that
+DistributedDataParallel issues over RCCL ("nccl" backend on ROCm) -- xGMI links on one node.  This
+module holds the small amount of glue around that: rendezvous from the torchrun environment, a
+barrier+synchronise fence for timing, max-over-ranks of a wall time and the per-rank data seed.
+It runs unchanged on the gloo backend (CPU), which is how the tests cover world_size 2.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_rank():
+    return int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1)), int(os.environ.get('LOCAL_RANK', 0))
+
+
+def setup(backend=None):
+    """Join the process group described by RANK / WORLD_SIZE / MASTER_* (no-op for one process).
+    Returns (rank, world_size, local_rank, device)."""
+    rank, world, local_rank = env_rank()
+    use_gpu = torch.cuda.is_available() and backend != 'gloo'
+    dev = torch.device('cuda', local_rank) if use_gpu else torch.device('cpu')
+    if use_gpu:
+        torch.cuda.set_device(dev)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        backend = backend or ('nccl' if use_gpu else 'gloo')
+        kw = {'device_id': dev} if backend == 'nccl' else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, world, local_rank, dev
+
+
+def fence(dev=None):
+    """Everything enqueued so far has finished on every rank."""
+    if torch.cuda.is_available() and (dev is None or dev.type == 'cuda'):
+        torch.cuda.synchronize()
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+        if torch.cuda.is_available() and (dev is None or dev.type == 'cuda'):
+            torch.cuda.synchronize()
+
+
+def max_over_ranks(seconds: float, dev) -> float:
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def data_seed(base: int, rank: int) -> int:
+    """Each rank draws its own synthetic cloud (weak scaling: per-GPU work is fixed)."""
+    return base + rank
+
+
+def whole_job_rate(units_per_rank_per_step: int, steps: int, world: int, seconds: float) -> float:
+    return world * units_per_rank_per_step * steps / seconds
+
+
+def wrap_ddp(module, dev):
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        ids = [dev.index] if dev.type == 'cuda' else None
+        return torch.nn.parallel.DistributedDataParallel(module, device_ids=ids)
+    return module
+
+
+def shutdown():
+    if dist.is_initialized():
+        dist.destroy_process_group()
