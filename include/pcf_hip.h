@@ -177,6 +177,28 @@ int pcf_hip_rowlin_backward(const float* x, const float* dy, long long R, int Ci
                             int batch_stats, int act, float* dx, float* dW, float* db, float* dgamma, float* dbeta,
                             void* workspace, size_t workspace_bytes, void* stream);
 
+/* Extended forms used by the first layer of the guidance MLP (MultiHeadGuidance, layers.py:47-68,
+ * fed by layers.py:372-381).  With W = [Wa | Wb] split at the gathered / positional halves of the
+ * query, W.(q - key) = (u[idx[e]] + Wb.pe[e]) - (the same for the key edge), u = Wa.guidance_x being a
+ * PER-POINT product: the 64-wide q - key tensor never exists.
+ *   gadd [B*gN, Cout] (u), gidx i64 [R] batch-local rows of gadd (the neighbour table), rows_per_batch = M*K;
+ *   group = K (power of two <= 64): subtract the pre-bias value of the group's first row (key = neighbour 0).
+ * Cout <= 16.  dgadd [B*gN, Cout] receives the gradient of gadd (zeroed here, float atomics). */
+int pcf_hip_rowlin_bn_stats_ex(const float* x, long long R, int Cin, const float* W, const float* b, int Cout, float eps,
+                               float momentum, float* running_mean, float* running_var, float* mean_out,
+                               float* rstd_out, const float* gadd, const int64_t* gidx, long long rows_per_batch,
+                               int gN, int group, void* workspace, size_t workspace_bytes, void* stream);
+int pcf_hip_rowlin_forward_ex(const float* x, long long R, int Cin, const float* W, const float* b, int Cout,
+                              const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
+                              const float* gadd, const int64_t* gidx, long long rows_per_batch, int gN, int group,
+                              float* y, void* stream);
+int pcf_hip_rowlin_backward_ex(const float* x, const float* dy, long long R, int Cin, const float* W, const float* b,
+                               int Cout, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                               int batch_stats, int act, const float* gadd, const int64_t* gidx,
+                               long long rows_per_batch, int gN, int group, float* dx, float* dW, float* db,
+                               float* dgamma, float* dbeta, float* dgadd, void* workspace, size_t workspace_bytes,
+                               void* stream);
+
 /* ---- guidance difference (query - key) --------------------------------------------------------
  * replaces layers.py:372-381 + layers.py:52-53: q = cat(index_points(guidance_x, nei), feat_pe),
  * key = q[:, :, :1] (self) or q.max(dim=2) (strided, use_max != 0), s = q - key.

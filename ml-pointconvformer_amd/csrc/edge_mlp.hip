@@ -47,6 +47,13 @@ struct RowLin {
     int Cin, Cout;
     int batch_stats;     // backward: BN used batch statistics
     int act;             // Act
+    // optional extras of the guidance first layer (Cout <= 16):
+    const float* gadd;       // [B*gN, Cout] per-point term gathered through gidx and added to x.W^T
+    const int64_t* gidx;     // [R] batch-local row of gadd for every row (out of range = no term)
+    float* dgadd;            // backward: [B*gN, Cout] float-atomic target (zeroed by the host wrapper)
+    long long rows_per_batch;
+    int gN;
+    int group;               // K (power of two <= 64): subtract the value of the group's first row; 0 = off
     int vec_x, vec_y;    // 16-byte row access allowed
 };
 
@@ -108,6 +115,35 @@ __device__ __forceinline__ float dot_row(const float (&x)[CIN], const float* wro
     return acc;
 }
 
+
+// Gathered additive row (guidance first layer): g[o] = gadd[b*gN + gidx[row]][o], zeros when absent.
+__device__ __forceinline__ long long gather_row_index(const RowLin& a, long long row, bool valid) {
+    if (!a.gadd || !valid) return -1;
+    const int64_t j = a.gidx[row];
+    if (j < 0 || j >= a.gN) return -1;
+    return (row / a.rows_per_batch) * a.gN + j;
+}
+__device__ __forceinline__ void load_gadd(const RowLin& a, long long grow, float (&g)[16]) {
+#pragma unroll
+    for (int o = 0; o < 16; ++o) g[o] = 0.f;
+    if (grow < 0) return;
+    const float* p = a.gadd + (size_t)grow * a.Cout;
+#pragma unroll
+    for (int o = 0; o < 16; ++o)
+        if (o < a.Cout) g[o] = p[o];
+}
+
+// Pre-activation of this lane's row for output o:  x.W[o] (+ gathered term) (- the same quantity of the
+// first row of the lane's group) + b[o].  Contains a wave shuffle: every lane of the wave must call it.
+template <int CIN>
+__device__ __forceinline__ float pre_act(const RowLin& a, const float (&x)[CIN], const float* sW, const float* sV, int o,
+                                         const float (&g)[16], int lane) {
+    float t = dot_row<CIN>(x, sW + o * CIN, 0.f);
+    if (a.gadd) t += g[o & 15];
+    if (a.group > 1) t -= __shfl(t, lane & ~(a.group - 1), WAVE);
+    return t + sV[o];
+}
+
 // Sum, over the 64 rows of a wave tile, of one or two per-row values for 16 channels: lane (o, q)
 // adds rows q*16 .. q*16+15 of channel o from the scratch tile(s).
 __device__ __forceinline__ void tile_colsum(const float* t1, const float* t2, int lane, float& s1, float& s2) {
@@ -157,6 +193,8 @@ __global__ __launch_bounds__(BLOCK) void rowlin_stats_kernel(const RowLin a) {
         const bool valid = row < a.R;
         float x[CIN];
         load_row<CIN>(a, row, valid, x);
+        float gv[16];
+        load_gadd(a, gather_row_index(a, row, valid), gv);
 #pragma unroll
         for (int ch = 0; ch < MAXCH; ++ch) {
             if (ch * OC < a.Cout) {
@@ -164,7 +202,8 @@ __global__ __launch_bounds__(BLOCK) void rowlin_stats_kernel(const RowLin a) {
                 for (int j = 0; j < OC; ++j) {
                     const int o = ch * OC + j;
                     float z = 0.f;
-                    if (o < a.Cout && valid) z = dot_row<CIN>(x, sW + o * CIN, sV[o]);
+                    if (o < a.Cout) z = pre_act<CIN>(a, x, sW, sV, o, gv, lane);
+                    if (!valid) z = 0.f;
                     t1[lane * ZS + j] = z;
                     t2[lane * ZS + j] = z * z;
                 }
@@ -240,9 +279,11 @@ __global__ __launch_bounds__(BLOCK) void rowlin_fwd_kernel(const RowLin a) {
     const long long ntiles = (a.R + WAVE - 1) / WAVE;
     for (long long t = (long long)blockIdx.x * NWAVE + wave; t < ntiles; t += (long long)gridDim.x * NWAVE) {
         const long long row = t * WAVE + lane;
-        if (row >= a.R) continue;
+        const bool valid = row < a.R;
         float x[CIN];
-        load_row<CIN>(a, row, true, x);
+        load_row<CIN>(a, row, valid, x);
+        float gv[16];
+        load_gadd(a, gather_row_index(a, row, valid), gv);
         float* yr = a.y + (size_t)row * a.Cout;
         for (int o0 = 0; o0 < a.Cout; o0 += 4) {
             float v[4];
@@ -251,12 +292,13 @@ __global__ __launch_bounds__(BLOCK) void rowlin_fwd_kernel(const RowLin a) {
                 const int o = o0 + j;
                 float u = 0.f;
                 if (o < a.Cout) {
-                    u = dot_row<CIN>(x, sW + o * CIN, sV[o]);
+                    u = pre_act<CIN>(a, x, sW, sV, o, gv, lane);
                     if (bn) u = (u - sV[64 + o]) * sV[128 + o] * sV[192 + o] + sV[256 + o];
                     u = act_fwd(ACT, u);
                 }
                 v[j] = u;
             }
+            if (!valid) continue;
             if (a.vec_y) st4(yr + o0, make_float4(v[0], v[1], v[2], v[3]));
             else {
 #pragma unroll
@@ -269,9 +311,9 @@ __global__ __launch_bounds__(BLOCK) void rowlin_fwd_kernel(const RowLin a) {
 
 // Per-row recomputation shared by the backward kernels: g = dy * act'(u), xhat.
 template <int CIN>
-__device__ __forceinline__ void row_grad(int ACT, const float (&x)[CIN], const float* sW, const float* sV, int o, bool bn,
-                                         float dyv, float& g, float& xhat) {
-    const float z = dot_row<CIN>(x, sW + o * CIN, sV[o]);
+__device__ __forceinline__ void row_grad(const RowLin& a, const float (&gv)[16], int lane, int ACT, const float (&x)[CIN],
+                                         const float* sW, const float* sV, int o, bool bn, float dyv, float& g, float& xhat) {
+    const float z = pre_act<CIN>(a, x, sW, sV, o, gv, lane);      // wave shuffle inside: all lanes call this
     float u = z;
     xhat = 0.f;
     if (bn) {
@@ -322,6 +364,8 @@ __global__ __launch_bounds__(BLOCK) void rowlin_bwd_reduce_kernel(const RowLin a
         const bool valid = row < a.R;
         float x[CIN];
         load_row<CIN>(a, row, valid, x);
+        float gv[16];
+        load_gadd(a, gather_row_index(a, row, valid), gv);
 #pragma unroll
         for (int ch = 0; ch < MAXCH; ++ch) {
             if (ch * OC < a.Cout) {
@@ -331,7 +375,8 @@ __global__ __launch_bounds__(BLOCK) void rowlin_bwd_reduce_kernel(const RowLin a
                 for (int j = 0; j < OC; ++j) {
                     const int o = ch * OC + j;
                     float g = 0.f, xh = 0.f;
-                    if (o < a.Cout && valid) row_grad<CIN>(ACT, x, sW, sV, o, true, d[j], g, xh);
+                    if (o < a.Cout) row_grad<CIN>(a, gv, lane, ACT, x, sW, sV, o, true, d[j], g, xh);
+                    if (!valid) { g = 0.f; xh = 0.f; }
                     t1[lane * ZS + j] = g;
                     t2[lane * ZS + j] = g * xh;
                 }
@@ -377,8 +422,10 @@ __global__ __launch_bounds__(BLOCK) void rowlin_bwd_apply_kernel(const RowLin a)
     float* sX = sV + 7 * 64;                        // per wave [64][XS]
     float* sD = sX + NWAVE * 64 * XS;               // per wave [64][DS]
     float* red = sD + NWAVE * 64 * DS;              // [64][NT*16] combine buffer + [64] db
+    int* sGi = reinterpret_cast<int*>(red + 64 * NT * 16 + 64);   // per wave [64] gather targets
     stage_weights<CIN>(a, sW, sV);
     const int lane = lane_id(), wave = wave_id();
+    int* gi = sGi + wave * 64;
     float* xt = sX + wave * 64 * XS;
     float* dt = sD + wave * 64 * DS;
     for (int u = lane; u < 64 * XS; u += WAVE) xt[u] = 0.f;     // pad columns stay zero for ever
@@ -401,6 +448,9 @@ __global__ __launch_bounds__(BLOCK) void rowlin_bwd_apply_kernel(const RowLin a)
 #pragma unroll
         for (int q = 0; q < CIN / 4; ++q)
             st4(xt + lane * XS + q * 4, make_float4(x[q * 4], x[q * 4 + 1], x[q * 4 + 2], x[q * 4 + 3]));
+        float gv[16];
+        const long long grow = gather_row_index(a, row, valid);
+        load_gadd(a, grow, gv);
         float dxr[CIN];
 #pragma unroll
         for (int i = 0; i < CIN; ++i) dxr[i] = 0.f;
@@ -409,16 +459,48 @@ __global__ __launch_bounds__(BLOCK) void rowlin_bwd_apply_kernel(const RowLin a)
             if (ch * OC < a.Cout) {
                 float d[OC];
                 load_dy16<CIN>(a, row, valid, ch * OC, d);
+                // dz = dL/d(pre-activation) for the 16 channels of this round
 #pragma unroll
                 for (int j = 0; j < OC; ++j) {
                     const int o = ch * OC + j;
                     float dz = 0.f;
-                    if (o < a.Cout && valid) {
+                    if (o < a.Cout) {
                         float g, xh;
-                        row_grad<CIN>(ACT, x, sW, sV, o, bn, d[j], g, xh);
+                        row_grad<CIN>(a, gv, lane, ACT, x, sW, sV, o, bn, d[j], g, xh);
                         dz = g;
                         if (bn) dz = sV[128 + o] * sV[192 + o] * (bstat ? (g - sV[320 + o] - xh * sV[384 + o]) : g);
-                        if (a.dx) {
+                    }
+                    d[j] = valid ? dz : 0.f;
+                }
+#pragma unroll
+                for (int q = 0; q < OC / 4; ++q)
+                    st4(dt + lane * DS + q * 4, make_float4(d[q * 4], d[q * 4 + 1], d[q * 4 + 2], d[q * 4 + 3]));
+                {   // db: column sums of the dz tile, lane (o, quarter)
+                    const float* p = dt + (fq * 16) * DS + fo;
+                    float sdb = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sdb += p[r * DS];
+                    dbs[ch] += sdb;
+                }
+                if (a.group > 1) {
+                    // z[k] = t[k] - t[first] + b  =>  dt[k] = dz[k] - [k is first] * sum over the group of dz
+                    const bool first = (lane & (a.group - 1)) == 0;
+#pragma unroll
+                    for (int j = 0; j < OC; ++j) {
+                        float tot = d[j];
+                        for (int off = 1; off < a.group; off <<= 1) tot += __shfl_xor(tot, off, WAVE);
+                        if (first) d[j] -= tot;
+                    }
+#pragma unroll
+                    for (int q = 0; q < OC / 4; ++q)
+                        st4(dt + lane * DS + q * 4, make_float4(d[q * 4], d[q * 4 + 1], d[q * 4 + 2], d[q * 4 + 3]));
+                }
+                if (a.dx) {
+#pragma unroll
+                    for (int j = 0; j < OC; ++j) {
+                        const int o = ch * OC + j;
+                        if (o < a.Cout) {
+                            const float dz = d[j];
                             const float* wr = sW + o * CIN;
 #pragma unroll
                             for (int q = 0; q < CIN / 4; ++q) {
@@ -430,12 +512,8 @@ __global__ __launch_bounds__(BLOCK) void rowlin_bwd_apply_kernel(const RowLin a)
                             }
                         }
                     }
-                    d[j] = dz;
                 }
-#pragma unroll
-                for (int q = 0; q < OC / 4; ++q)
-                    st4(dt + lane * DS + q * 4, make_float4(d[q * 4], d[q * 4 + 1], d[q * 4 + 2], d[q * 4 + 3]));
-                // dW[o][i] += sum_rows dz[row][o] * x[row][i]   (A = dz^T, B = x), 16 k-steps of 4 rows
+                // dW[o][i] += sum_rows dt[row][o] * x[row][i]   (A = dt^T, B = x), 16 k-steps of 4 rows
 #pragma unroll
                 for (int s = 0; s < 16; ++s) {
                     const float av = dt[(s * 4 + fq) * DS + fo];
@@ -445,12 +523,16 @@ __global__ __launch_bounds__(BLOCK) void rowlin_bwd_apply_kernel(const RowLin a)
                         acc[ch][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[ch][nt], 0, 0, 0);
                     }
                 }
-                {   // db: column sums of the dz tile, lane (o, quarter)
-                    const float* p = dt + (fq * 16) * DS + fo;
-                    float sdb = 0.f;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) sdb += p[r * DS];
-                    dbs[ch] += sdb;
+                if (a.dgadd && ch == 0) {
+                    // scatter dt into the per-point table: lanes walk the tile as (row, channel) pairs so that
+                    // one wave instruction covers whole rows of the table.
+                    gi[lane] = (int)grow;                        // -1 = no target; tables are < 2^31 rows
+                    const int C = a.Cout;
+                    for (int e = lane; e < WAVE * C; e += WAVE) {
+                        const int r = e / C, o = e - r * C;
+                        const int tgt = gi[r];
+                        if (tgt >= 0) atomicAdd(a.dgadd + (size_t)tgt * C + o, dt[r * DS + o]);
+                    }
                 }
             }
         }
@@ -552,7 +634,7 @@ static size_t lds_stats(int CT) { return (size_t)(64 * CT + 7 * 64 + NWAVE * 2 *
 static size_t lds_fwd(int CT) { return (size_t)(64 * CT + 7 * 64) * 4; }
 static size_t lds_apply(int CT) {
     const int NT = (CT + 15) / 16;
-    return (size_t)(64 * CT + 7 * 64 + NWAVE * 64 * tile_stride(CT) + NWAVE * 64 * tile_stride(OC) + 64 * NT * 16 + 64) * 4;
+    return (size_t)(64 * CT + 7 * 64 + NWAVE * 64 * tile_stride(CT) + NWAVE * 64 * tile_stride(OC) + 64 * NT * 16 + 64 + NWAVE * 64) * 4;
 }
 static size_t part_floats_stats(int grid) { return (size_t)grid * 128; }
 static size_t part_floats_apply(int grid, int CT) { return (size_t)grid * (64 * ((CT + 15) / 16) * 16 + 64); }
@@ -596,11 +678,25 @@ size_t pcf_hip_rowlin_workspace_bytes(int Cin, int Cout) {
     return (std::max(a, b) + 4 * 64) * 4 + 256;
 }
 
-int pcf_hip_rowlin_bn_stats(const float* x, long long R, int Cin, const float* W, const float* b, int Cout, float eps,
-                            float momentum, float* running_mean, float* running_var, float* mean_out, float* rstd_out,
-                            void* workspace, size_t workspace_bytes, void* stream) {
+static int check_extras(const char* who, long long R, int Cout, const float* gadd, const int64_t* gidx,
+                        long long rows_per_batch, int gN, int group) {
+    using namespace pcf;
+    if (!gadd && group <= 1) return PCF_OK;
+    if (Cout > 16) return fail(PCF_E_UNSUPPORTED, "%s: gathered term / key subtraction need Cout <= 16 (got %d)", who, Cout);
+    if (gadd) PCF_REQUIRE(gidx && gN >= 0 && rows_per_batch > 0 && R % rows_per_batch == 0,
+                          "%s: gathered term needs gidx, gN >= 0 and rows_per_batch dividing R", who);
+    if (group > 1) PCF_REQUIRE(group <= 64 && (group & (group - 1)) == 0 && R % group == 0,
+                               "%s: group must be a power of two <= 64 dividing R (got %d)", who, group);
+    return PCF_OK;
+}
+
+int pcf_hip_rowlin_bn_stats_ex(const float* x, long long R, int Cin, const float* W, const float* b, int Cout, float eps,
+                               float momentum, float* running_mean, float* running_var, float* mean_out, float* rstd_out,
+                               const float* gadd, const int64_t* gidx, long long rows_per_batch, int gN, int group,
+                               void* workspace, size_t workspace_bytes, void* stream) {
     using namespace pcf;
     if (int e = check_rowlin("rowlin_bn_stats", R, Cin, Cout, 0)) return e;
+    if (int e = check_extras("rowlin_bn_stats", R, Cout, gadd, gidx, rows_per_batch, gN, group)) return e;
     PCF_REQUIRE(R > 0, "rowlin_bn_stats: batch statistics of zero rows");
     PCF_REQUIRE(x && W && b && mean_out && rstd_out && workspace, "rowlin_bn_stats: null pointer");
     PCF_REQUIRE(workspace_bytes >= pcf_hip_rowlin_workspace_bytes(Cin, Cout) && aligned16(workspace),
@@ -611,6 +707,7 @@ int pcf_hip_rowlin_bn_stats(const float* x, long long R, int Cin, const float* W
     const int grid = rowlin_grid(R);
     RowLin a{};
     a.x = x; a.W = W; a.b = b; a.R = R; a.Cin = Cin; a.Cout = Cout;
+    a.gadd = gadd; a.gidx = gidx; a.rows_per_batch = rows_per_batch; a.gN = gN; a.group = group;
     a.part = static_cast<float*>(workspace);
     a.vec_x = (Cin % 4 == 0) && aligned16(x);
     int rc = PCF_OK;
@@ -621,39 +718,64 @@ int pcf_hip_rowlin_bn_stats(const float* x, long long R, int Cin, const float* W
     return check_launch("per-edge linear: BN finalize");
 }
 
-int pcf_hip_rowlin_forward(const float* x, long long R, int Cin, const float* W, const float* b, int Cout,
-                           const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
-                           float* y, void* stream) {
+int pcf_hip_rowlin_bn_stats(const float* x, long long R, int Cin, const float* W, const float* b, int Cout, float eps,
+                            float momentum, float* running_mean, float* running_var, float* mean_out, float* rstd_out,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+    return pcf_hip_rowlin_bn_stats_ex(x, R, Cin, W, b, Cout, eps, momentum, running_mean, running_var, mean_out, rstd_out,
+                                      nullptr, nullptr, 0, 0, 0, workspace, workspace_bytes, stream);
+}
+
+int pcf_hip_rowlin_forward_ex(const float* x, long long R, int Cin, const float* W, const float* b, int Cout,
+                              const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
+                              const float* gadd, const int64_t* gidx, long long rows_per_batch, int gN, int group,
+                              float* y, void* stream) {
     using namespace pcf;
     if (int e = check_rowlin("rowlin_forward", R, Cin, Cout, act)) return e;
+    if (int e = check_extras("rowlin_forward", R, Cout, gadd, gidx, rows_per_batch, gN, group)) return e;
     if (R == 0) return ok();
     PCF_REQUIRE(x && W && b && y, "rowlin_forward: null pointer");
     PCF_REQUIRE(!mean || (rstd && gamma && beta), "rowlin_forward: BN needs mean, rstd, gamma and beta");
     const int CT = cin_template(Cin);
     RowLin a{};
     a.x = x; a.y = y; a.W = W; a.b = b; a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.beta = beta;
-    a.R = R; a.Cin = Cin; a.Cout = Cout;
+    a.R = R; a.Cin = Cin; a.Cout = Cout; a.act = act;
+    a.gadd = gadd; a.gidx = gidx; a.rows_per_batch = rows_per_batch; a.gN = gN; a.group = group;
     a.vec_x = (Cin % 4 == 0) && aligned16(x);
     a.vec_y = (Cout % 4 == 0) && aligned16(y);
     int rc = PCF_OK;
-    a.act = act;
     PCF_CIN_SWITCH(CT, rc = launch_rowlin(rowlin_fwd_kernel<C>, a, rowlin_grid(R), lds_fwd(C), (hipStream_t)stream,
                                           "per-edge linear forward"));
     return rc;
 }
 
-int pcf_hip_rowlin_backward(const float* x, const float* dy, long long R, int Cin, const float* W, const float* b,
-                            int Cout, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                            int batch_stats, int act, float* dx, float* dW, float* db, float* dgamma, float* dbeta,
-                            void* workspace, size_t workspace_bytes, void* stream) {
+int pcf_hip_rowlin_forward(const float* x, long long R, int Cin, const float* W, const float* b, int Cout,
+                           const float* mean, const float* rstd, const float* gamma, const float* beta, int act,
+                           float* y, void* stream) {
+    return pcf_hip_rowlin_forward_ex(x, R, Cin, W, b, Cout, mean, rstd, gamma, beta, act, nullptr, nullptr, 0, 0, 0, y, stream);
+}
+
+int pcf_hip_rowlin_backward_ex(const float* x, const float* dy, long long R, int Cin, const float* W, const float* b,
+                               int Cout, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                               int batch_stats, int act, const float* gadd, const int64_t* gidx, long long rows_per_batch,
+                               int gN, int group, float* dx, float* dW, float* db, float* dgamma, float* dbeta,
+                               float* dgadd, void* workspace, size_t workspace_bytes, void* stream) {
     using namespace pcf;
     if (int e = check_rowlin("rowlin_backward", R, Cin, Cout, act)) return e;
+    if (int e = check_extras("rowlin_backward", R, Cout, gadd, gidx, rows_per_batch, gN, group)) return e;
     PCF_REQUIRE(W && b && dW && db && workspace, "rowlin_backward: null pointer");
     PCF_REQUIRE(workspace_bytes >= pcf_hip_rowlin_workspace_bytes(Cin, Cout) && aligned16(workspace),
                 "rowlin_backward: workspace too small or misaligned");
+    PCF_REQUIRE(!gadd || dgadd, "rowlin_backward: gathered term given but its gradient buffer is null");
     const bool bn = mean != nullptr;
     PCF_REQUIRE(!bn || (rstd && gamma && beta && dgamma && dbeta), "rowlin_backward: BN needs rstd/gamma/beta and their grads");
     hipStream_t s = (hipStream_t)stream;
+    if (gadd && rows_per_batch > 0) {
+        const size_t n = (size_t)(R / rows_per_batch) * gN * Cout;
+        if (n) {
+            hipError_t e = hipMemsetAsync(dgadd, 0, n * 4, s);
+            if (e != hipSuccess) return fail(PCF_E_LAUNCH, "rowlin_backward: memset: %s", hipGetErrorString(e));
+        }
+    }
     if (R == 0) {
         (void)hipMemsetAsync(dW, 0, (size_t)Cout * Cin * 4, s);
         (void)hipMemsetAsync(db, 0, (size_t)Cout * 4, s);
@@ -670,6 +792,7 @@ int pcf_hip_rowlin_backward(const float* x, const float* dy, long long R, int Ci
     RowLin a{};
     a.x = x; a.dy = dy; a.dx = dx; a.W = W; a.b = b; a.mean = mean; a.rstd = rstd; a.gamma = gamma; a.beta = beta;
     a.R = R; a.Cin = Cin; a.Cout = Cout; a.batch_stats = batch_stats; a.part = part; a.act = act;
+    a.gadd = gadd; a.gidx = gidx; a.dgadd = gadd ? dgadd : nullptr; a.rows_per_batch = rows_per_batch; a.gN = gN; a.group = group;
     a.vec_x = (Cin % 4 == 0) && aligned16(x) && (!dx || aligned16(dx));
     a.vec_y = (Cout % 4 == 0) && aligned16(dy);
     int rc = PCF_OK;
@@ -688,6 +811,14 @@ int pcf_hip_rowlin_backward(const float* x, const float* dy, long long R, int Ci
     hipLaunchKernelGGL(rowlin_param_reduce_kernel, dim3(ceil_div(Cout * Cin + Cout, 64)), dim3(BLOCK), 0, s, part, grid,
                        PW, Cin, Cout, dW, db);
     return check_launch("per-edge linear: parameter-gradient reduction");
+}
+
+int pcf_hip_rowlin_backward(const float* x, const float* dy, long long R, int Cin, const float* W, const float* b,
+                            int Cout, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                            int batch_stats, int act, float* dx, float* dW, float* db, float* dgamma, float* dbeta,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+    return pcf_hip_rowlin_backward_ex(x, dy, R, Cin, W, b, Cout, mean, rstd, gamma, beta, batch_stats, act, nullptr, nullptr,
+                                      0, 0, 0, dx, dW, db, dgamma, dbeta, nullptr, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

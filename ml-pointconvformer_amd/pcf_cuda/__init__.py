@@ -105,20 +105,23 @@ def _stream(dev):
     return torch.cuda.current_stream(dev).cuda_stream
 
 
-_timeline = None   # when a list: (entry point name, start event, end event) per C-ABI call
+_timeline = None   # when a list: (entry point name, start event, end event) per bracketed C-ABI call
+_timeline_only = None
 
 
-def record_kernel_times(enable: bool):
-    """Bracket every C-ABI call with HIP events on the stream it is enqueued on (torch's current
-    stream); returns the list being filled, or None when disabled.  Used by bench.py to measure the
-    dominant kernel live inside the timed region."""
-    global _timeline
+def record_kernel_times(enable: bool, only=None):
+    """Bracket C-ABI calls with HIP events on the stream they are enqueued on (torch's current stream);
+    returns the list being filled, or None when disabled.  ``only`` restricts the bracketing to a set of
+    entry-point names: an event pair costs the host several microseconds, so bench.py brackets just the
+    dominant kernel inside the timed region and everything in a separate, untimed pass."""
+    global _timeline, _timeline_only
     _timeline = [] if enable else None
+    _timeline_only = set(only) if (enable and only) else None
     return _timeline
 
 
 def _call(fn, *args):
-    if _timeline is None:
+    if _timeline is None or (_timeline_only is not None and fn.__name__ not in _timeline_only):
         rc = fn(*args)
     else:
         t0 = torch.cuda.Event(enable_timing=True)

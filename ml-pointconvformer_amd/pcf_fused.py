@@ -140,10 +140,12 @@ _F = ctypes.c_float
 _rowlin_ws = getattr(_lib, 'pcf_hip_rowlin_workspace_bytes')
 _rowlin_ws.argtypes = [_I, _I]
 _rowlin_ws.restype = _Z
-_rowlin_stats = _sig('pcf_hip_rowlin_bn_stats', [_P, _LL, _I, _P, _P, _I, _F, _F, _P, _P, _P, _P, _P, _Z, _P])
-_rowlin_fwd = _sig('pcf_hip_rowlin_forward', [_P, _LL, _I, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P])
-_rowlin_bwd = _sig('pcf_hip_rowlin_backward', [_P, _P, _LL, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I,
-                                               _P, _P, _P, _P, _P, _P, _Z, _P])
+_rowlin_stats = _sig('pcf_hip_rowlin_bn_stats_ex', [_P, _LL, _I, _P, _P, _I, _F, _F, _P, _P, _P, _P,
+                                                    _P, _P, _LL, _I, _I, _P, _Z, _P])
+_rowlin_fwd = _sig('pcf_hip_rowlin_forward_ex', [_P, _LL, _I, _P, _P, _I, _P, _P, _P, _P, _I,
+                                                 _P, _P, _LL, _I, _I, _P, _P])
+_rowlin_bwd = _sig('pcf_hip_rowlin_backward_ex', [_P, _P, _LL, _I, _P, _P, _I, _P, _P, _P, _P, _I, _I,
+                                                  _P, _P, _LL, _I, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _P])
 _gdiff_fwd = _sig('pcf_hip_guidance_diff_forward', [_P] * 5 + [_I] * 7 + [_P])
 _gdiff_bwd = _sig('pcf_hip_guidance_diff_backward', [_P] * 5 + [_I] * 6 + [_P])
 
@@ -157,13 +159,21 @@ class _LinearBNAct(torch.autograd.Function):
     statistics when `training`, running statistics otherwise; gamma None = no BN)."""
 
     @staticmethod
-    def forward(ctx, x, W, b, gamma, beta, running_mean, running_var, eps, momentum, training, act):
+    def forward(ctx, x, W, b, gamma, beta, running_mean, running_var, eps, momentum, training, act,
+                gadd=None, gidx=None, group=0):
         x = x.contiguous()
         W, b = W.contiguous(), b.contiguous()
         Cout, Cin = W.shape
         R = x.numel() // Cin
         dev = x.device
         bn = gamma is not None
+        if gadd is not None:
+            gadd = gadd.contiguous()
+            gN = gadd.shape[-2]
+            rpb = gidx[0].numel()
+        else:
+            gN, rpb = 0, 0
+        extras = (_ptr(gadd), _ptr(gidx) if gadd is not None else None, rpb, gN, int(group))
         mean = rstd = None
         stream = _stream(dev)
         with torch.cuda.device(dev):
@@ -174,21 +184,22 @@ class _LinearBNAct(torch.autograd.Function):
                     nbytes = _rowlin_ws(Cin, Cout)
                     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
                     _call(_rowlin_stats, _ptr(x), R, Cin, _ptr(W), _ptr(b), Cout, float(eps), float(momentum),
-                          _ptr(running_mean), _ptr(running_var), _ptr(mean), _ptr(rstd), ws.data_ptr(), nbytes, stream)
+                          _ptr(running_mean), _ptr(running_var), _ptr(mean), _ptr(rstd), *extras,
+                          ws.data_ptr(), nbytes, stream)
                 else:
                     mean = running_mean
                     rstd = torch.rsqrt(running_var + eps)
             y = torch.empty(*x.shape[:-1], Cout, dtype=torch.float32, device=dev)
             _call(_rowlin_fwd, _ptr(x), R, Cin, _ptr(W), _ptr(b), Cout, _ptr(mean), _ptr(rstd),
-                  _ptr(gamma) if bn else None, _ptr(beta) if bn else None, int(act), _ptr(y), stream)
-        ctx.save_for_backward(x, W, b, gamma, beta, mean, rstd)
-        ctx.cfg = (bool(training), int(act), bn)
+                  _ptr(gamma) if bn else None, _ptr(beta) if bn else None, int(act), *extras, _ptr(y), stream)
+        ctx.save_for_backward(x, W, b, gamma, beta, mean, rstd, gadd, gidx if gadd is not None else None)
+        ctx.cfg = (bool(training), int(act), bn, rpb, gN, int(group))
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, W, b, gamma, beta, mean, rstd = ctx.saved_tensors
-        training, act, bn = ctx.cfg
+        x, W, b, gamma, beta, mean, rstd, gadd, gidx = ctx.saved_tensors
+        training, act, bn, rpb, gN, group = ctx.cfg
         dy = dy.contiguous()
         Cout, Cin = W.shape
         R = x.numel() // Cin
@@ -198,28 +209,44 @@ class _LinearBNAct(torch.autograd.Function):
         db = torch.empty_like(b)
         dgamma = torch.empty_like(gamma) if bn else None
         dbeta = torch.empty_like(beta) if bn else None
+        dgadd = torch.empty_like(gadd) if gadd is not None else None
         nbytes = _rowlin_ws(Cin, Cout)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
             _call(_rowlin_bwd, _ptr(x), _ptr(dy), R, Cin, _ptr(W), _ptr(b), Cout, _ptr(mean), _ptr(rstd),
                   _ptr(gamma) if bn else None, _ptr(beta) if bn else None, 1 if training else 0, act,
-                  _ptr(dx), _ptr(dW), _ptr(db), _ptr(dgamma), _ptr(dbeta), ws.data_ptr(), nbytes, _stream(dev))
-        return dx, dW, db, dgamma, dbeta, None, None, None, None, None, None
+                  _ptr(gadd), _ptr(gidx), rpb, gN, group,
+                  _ptr(dx), _ptr(dW), _ptr(db), _ptr(dgamma), _ptr(dbeta), _ptr(dgadd), ws.data_ptr(), nbytes, _stream(dev))
+        return dx, dW, db, dgamma, dbeta, None, None, None, None, None, None, dgadd, None, None
 
 
-def linear_bn_act(x, weight, bias, bn, act, training):
-    """Fused Linear (+BatchNorm1d module `bn`, or None) (+activation) on the last axis of x."""
+def linear_bn_act(x, weight, bias, bn, act, training, gadd=None, gidx=None, group=0):
+    """Fused Linear (+BatchNorm1d module `bn`, or None) (+activation) on the last axis of x.
+
+    Optional extras (first layer of the guidance MLP, Cout <= 16): ``gadd`` [B,N,Cout] is gathered
+    through ``gidx`` [B,M,K] and added to x.W^T; ``group`` = K subtracts the pre-bias value of the first
+    row of every group of K rows (key = neighbour 0)."""
+    x, weight, bias = x.contiguous(), weight.contiguous(), bias.contiguous()   # slices of a parameter are fine
     _floats(x=x, weight=weight, bias=bias)
     if x.shape[-1] != weight.shape[1]:
         raise RuntimeError(f'linear_bn_act: input has {x.shape[-1]} channels, weight expects {weight.shape[1]}')
+    if gadd is not None:
+        gadd = gadd.contiguous()
+        _floats(gadd=gadd)
+        _check_input(gidx, 'gidx', torch.int64)
     if bn is None:
-        return _LinearBNAct.apply(x, weight, bias, None, None, None, None, 0.0, 0.0, False, act)
+        return _LinearBNAct.apply(x, weight, bias, None, None, None, None, 0.0, 0.0, False, act, gadd, gidx, group)
     use_batch = training or bn.running_mean is None
     if training and bn.num_batches_tracked is not None:
         bn.num_batches_tracked += 1
     momentum = 0.1 if bn.momentum is None else bn.momentum
     return _LinearBNAct.apply(x, weight, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, momentum,
-                              use_batch, act)
+                              use_batch, act, gadd, gidx, group)
+
+
+def split_guidance_supported(K, cout):
+    """The gathered-term / key-subtraction form needs K a power of two <= 64 and Cout <= 16."""
+    return 1 <= K <= 64 and (K & (K - 1)) == 0 and cout <= 16
 
 
 class _GuidanceDiff(torch.autograd.Function):

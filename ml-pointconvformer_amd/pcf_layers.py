@@ -222,6 +222,26 @@ class MultiHeadGuidance(nn.Module):
     def forward(self, guidance_query, guidance_key):
         return self.forward_diff(guidance_query - guidance_key)
 
+    def forward_split(self, guidance_x, nei_inds, feat_pe):
+        """Scores for SELF neighbourhoods (key = neighbour 0) without forming the query tensor.
+
+        With the first layer's weight split as W = [Wa | Wb] over the gathered / positional halves,
+        W.(q - key) = (u[idx] + Wb.pe) - (same for the key edge) where u = Wa.guidance_x is a per-point
+        product: an 8-wide gather replaces the [B,M,K,2G] query, key and difference tensors."""
+        first = self.mlp[0]
+        lin = first.c if isinstance(first, Linear_BN) else first
+        bn = first.bn if isinstance(first, Linear_BN) else None
+        G = guidance_x.shape[-1]
+        W = lin.weight
+        u = pcf_fused.linear_bn_act(guidance_x, W[:, :G], W.new_zeros(W.shape[0]), None, pcf_fused.ACT_NONE, self.training)
+        last = len(self.mlp) - 1
+        s = pcf_fused.linear_bn_act(feat_pe, W[:, G:], lin.bias, bn,
+                                    pcf_fused.ACT_SIGMOID if last == 0 else pcf_fused.ACT_RELU, self.training,
+                                    gadd=u, gidx=nei_inds, group=nei_inds.shape[2])
+        for i in range(1, len(self.mlp)):
+            s = _linear_act(self.mlp[i], s, pcf_fused.ACT_SIGMOID if i == last else pcf_fused.ACT_RELU)
+        return s
+
     def forward_diff(self, s):
         """Scores from the already-formed difference query - key."""
         last = len(self.mlp) - 1
@@ -299,9 +319,14 @@ class PCFLayer(nn.Module):
                                   vi_features)
         feat_pe = _linear_act(self.mlp_conv, wn_in, pcf_fused.ACT_RELU)
         guidance_x = self.guidance_unary(feats_x)
-        # query - key in one kernel: key = neighbour 0 (self) or the max over the neighbourhood (strided)
-        diff = pcf_fused.guidance_diff(guidance_x.contiguous(), nei_inds, feat_pe, use_max=strided)
-        guidance_score = self.guidance_weight.forward_diff(diff)
+        if not strided and pcf_fused.split_guidance_supported(nei_inds.shape[2], 8) \
+                and pcf_fused.rowlin_supported(feat_pe.shape[-1], 8):
+            # self neighbourhoods: key = neighbour 0; the first guidance layer absorbs the q - key algebra
+            guidance_score = self.guidance_weight.forward_split(guidance_x.contiguous(), nei_inds, feat_pe)
+        else:
+            # strided: key = max over the neighbourhood, formed explicitly in one kernel
+            diff = pcf_fused.guidance_diff(guidance_x.contiguous(), nei_inds, feat_pe, use_max=strided)
+            guidance_score = self.guidance_weight.forward_diff(diff)
         weights = self.weightnet(wn_in)
         agg = PCF.forward(feats_x.contiguous(), nei_inds, guidance_score.contiguous(), weights.contiguous())
         new_feat = self.unary2(self.dropout(_linear_act(self.linear, agg, pcf_fused.ACT_RELU)))

@@ -265,3 +265,52 @@ def test_guidance_diff_against_torch(device, use_max):
     torch.testing.assert_close(got.cpu(), want, rtol=0, atol=0)
     torch.testing.assert_close(pd.grad.cpu(), pr.grad, rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(gd.grad.cpu(), gr.grad, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('K,bn', [(16, True), (8, True), (4, False), (64, True)])
+def test_split_guidance_first_layer(device, K, bn):
+    """linear_bn_act with the gathered per-point term and key subtraction == Linear_BN(q - key) formed
+    explicitly (layers.py:372-382), outputs and all gradients, vs torch fp64 on the CPU."""
+    import pcf_fused
+    from oracle import pcf_oracle as O
+    g = torch.Generator().manual_seed(K)
+    B, N, G, P, Cout = 2, 70, 32, 32, 8
+    M = N
+    gx = torch.randn(B, N, G, generator=g)
+    pe = torch.randn(B, M, K, P, generator=g)
+    idx = torch.randint(0, N, (B, M, K), generator=g)
+    W = torch.randn(Cout, G + P, generator=g) / 8
+    b = torch.randn(Cout, generator=g)
+    gam, bet = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1
+    # reference in fp64
+    gr, pr, Wr, br = (t.double().requires_grad_(True) for t in (gx, pe, W, b))
+    gamr, betr = gam.double().requires_grad_(True), bet.double().requires_grad_(True)
+    q = torch.cat([O.gather_rows(gr, idx), pr], -1)
+    z = torch.nn.functional.linear(q - q[:, :, :1], Wr, br)
+    if bn:
+        flat = z.reshape(-1, Cout)
+        z = ((flat - flat.mean(0)) / torch.sqrt(flat.var(0, unbiased=False) + 1e-5) * gamr + betr).view(z.shape)
+    want = torch.relu(z)
+    up = torch.randn(want.shape, generator=g)
+    want.backward(up.double())
+    # HIP
+    d = lambda t: t.to(device).requires_grad_(True)
+    gd, pd, Wd, bd = d(gx), d(pe), d(W), d(b)
+    bnm = None
+    if bn:
+        bnm = torch.nn.BatchNorm1d(Cout).to(device).train()
+        with torch.no_grad():
+            bnm.weight.copy_(gam); bnm.bias.copy_(bet)
+    u = pcf_fused.linear_bn_act(gd, Wd[:, :G], torch.zeros(Cout, device=device), None, 0, True)
+    got = pcf_fused.linear_bn_act(pd, Wd[:, G:], bd, bnm, 1, True, gadd=u, gidx=idx.to(device), group=K)
+    got.backward(up.to(device))
+    tol = dict(rtol=3e-4, atol=3e-4)
+    torch.testing.assert_close(got.cpu(), want.float(), **tol)
+    torch.testing.assert_close(pd.grad.cpu(), pr.grad.float(), **tol)
+    torch.testing.assert_close(gd.grad.cpu(), gr.grad.float(), **tol)
+    sc = max(1.0, float(Wr.grad.abs().max()))
+    torch.testing.assert_close(Wd.grad.cpu(), Wr.grad.float(), rtol=3e-4, atol=3e-4 * sc)
+    torch.testing.assert_close(bd.grad.cpu(), br.grad.float(), rtol=3e-4, atol=3e-3 * sc)
+    if bn:
+        torch.testing.assert_close(bnm.weight.grad.cpu(), gamr.grad.float(), rtol=3e-4, atol=3e-4 * sc)
+        torch.testing.assert_close(bnm.bias.grad.cpu(), betr.grad.float(), rtol=3e-4, atol=3e-4 * sc)
