@@ -70,7 +70,8 @@ def cpu_baseline(state_dict, xyz, nrm, feats, idx, iters=3):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    torch.set_num_threads(max(1, cores))
+    cores = max(1, min(cores, 16))        # a 1-GPU box's CPU share; more threads than that only thrash
+    torch.set_num_threads(cores)
     sd = {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point() and 'running' not in k)
           for k, v in state_dict.items()}
     P = O.Params(sd, '', True)
