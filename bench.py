@@ -105,6 +105,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--points', type=int, default=N_POINTS)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--deterministic', action='store_true',
+                    help='grad_x by CSR gather-reduce (bitwise reproducible) instead of float atomics')
     args = ap.parse_args()
 
     import pcf_dist
@@ -120,7 +122,9 @@ def main():
     import pcf_layers
 
     torch.manual_seed(1)
-    layer = pcf_layers.PCFLayer(C_FEAT, C_FEAT, layer_cfg(), weightnet=[12, C_MID], num_heads=HEADS,
+    cfg = layer_cfg()
+    cfg['DETERMINISTIC_BACKWARD'] = bool(args.deterministic)
+    layer = pcf_layers.PCFLayer(C_FEAT, C_FEAT, cfg, weightnet=[12, C_MID], num_heads=HEADS,
                                 guidance_feat_len=GUID).to(dev).train()
     model = pcf_dist.wrap_ddp(layer, dev)
 
@@ -135,8 +139,17 @@ def main():
     torch.cuda.synchronize()
     knn_ms = (time.perf_counter() - t0) * 1e3
 
+    # inverse CSR of the neighbour table, built once per cloud like the kNN (the training loop does it
+    # per iteration next to the kNN: train_ScanNet_DDP_WarmUP.py:401); reported as csr_ms
+    pcf_cuda.compute_knn_inverse(idx, n)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    inv_n, inv_k, inv_idx = pcf_cuda.compute_knn_inverse(idx, n)
+    torch.cuda.synchronize()
+    csr_ms = (time.perf_counter() - t0) * 1e3
+
     def step():
-        out, _ = model(xyz, feats, idx, nrm)
+        out, _ = model(xyz, feats, idx, nrm, None, None, None, inv_n, inv_k, inv_idx)
         out.sum().backward()
         for p in layer.parameters():
             p.grad = None
@@ -149,7 +162,7 @@ def main():
 
     # HIP events around the launches of the aggregate kernels only (the roofline candidates): an event
     # pair per call on all ~45 entry points of a step would cost the host more than a millisecond.
-    DOMINANT = ('pcf_hip_pcf_forward', 'pcf_hip_pcf_backward')
+    DOMINANT = ('pcf_hip_pcf_forward', 'pcf_hip_pcf_backward', 'pcf_hip_pcf_backward_csr')
     timeline = pcf_cuda.record_kernel_times(True, only=DOMINANT)
     fence()
     t0 = time.perf_counter()
@@ -181,7 +194,8 @@ def main():
         Ci = C_FEAT // 4
         fwd_b, bwd_b = _agg_bytes(Ci, C_MID, HEADS, K_NEI)
         cand = {'pcf_hip_pcf_forward': (fwd_b, 'agg_fwd_kernel<16,true>'),
-                'pcf_hip_pcf_backward': (bwd_b, 'agg_bwd_kernel<16,true,true>')}
+                'pcf_hip_pcf_backward': (bwd_b, 'agg_bwd_kernel<16,true,true>'),
+                'pcf_hip_pcf_backward_csr': (bwd_b, 'agg_bwd_kernel<16,true,false> + csr_reduce_kernel')}
         dom = max((k for k in cand if k in hip_ms), key=lambda k: hip_ms[k])
         bytes_per_launch = cand[dom][0] * n
         achieved = bytes_per_launch / (hip_ms[dom] * 1e-3) / 1e9
@@ -202,7 +216,7 @@ def main():
             'roofline': roofline,
             'hip_ms_per_call': {k: round(v, 4) for k, v in sorted(hip_ms_all.items())},
             'hip_ms_per_step': round(hip_total_ms, 4),
-            'knn_ms': round(knn_ms, 3),
+            'knn_ms': round(knn_ms, 3), 'csr_ms': round(csr_ms, 3),
         }
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(layer.state_dict(), xyz, nrm, feats.detach(), idx)

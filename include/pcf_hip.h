@@ -58,6 +58,16 @@ int pcf_hip_pcf_backward(const float* grad_out, const float* x, const int64_t* i
                          const float* w, float* grad_x, float* grad_guid, float* grad_w, int B, int N,
                          int Nout, int K, int Ci, int Cm, int H, void* stream);
 
+/* pcf_backward with grad_x as a deterministic gather-reduce over the inverse CSR (no atomics): the
+ * PCFLayer receives inv_neighbors / inv_k / inv_idx from the model (layers.py:315-317) but the
+ * reference never uses them there.  Workspace holds one contribution row per edge. */
+size_t pcf_hip_pcf_backward_csr_workspace_bytes(int B, int Nout, int K, int Ci);
+int pcf_hip_pcf_backward_csr(const float* grad_out, const float* x, const int32_t* inv_neighbors, const uint8_t* inv_k,
+                             const int32_t* inv_idx, const int64_t* idx, const float* guid, const float* w,
+                             float* grad_x, float* grad_guid, float* grad_w, void* workspace, size_t workspace_bytes,
+                             int B, int N, int Nout, int K, int Ci, int Cm, int H, int inv_len, int inv_idx_len,
+                             void* stream);
+
 /* ---- unguided aggregate with appended per-edge features (PConv) ------------------------------
  * replaces pcf_cuda.pconv_forward / pconv_backward     (pcf_cuda.cpp:12,14, pcf.h:81-112,
  *                                                       pconv_ops.cu:40-103,240-290,648-776)

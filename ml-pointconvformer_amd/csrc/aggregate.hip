@@ -571,4 +571,34 @@ int pcf_hip_pconv_backward(const float* grad_out, const float* x, const int64_t*
                                    Nout, K, Ci, Ca, Cm, 1, (hipStream_t)stream);
 }
 
+size_t pcf_hip_pcf_backward_csr_workspace_bytes(int B, int Nout, int K, int Ci) {
+    if (B < 0 || Nout < 0 || K < 0 || Ci < 0) return 0;
+    return (size_t)B * Nout * K * Ci * sizeof(float) + 256;
+}
+
+int pcf_hip_pcf_backward_csr(const float* grad_out, const float* x, const int32_t* inv_neighbors, const uint8_t* inv_k,
+                             const int32_t* inv_idx, const int64_t* idx, const float* guid, const float* w,
+                             float* grad_x, float* grad_guid, float* grad_w, void* workspace, size_t workspace_bytes,
+                             int B, int N, int Nout, int K, int Ci, int Cm, int H, int inv_len, int inv_idx_len,
+                             void* stream) {
+    using namespace pcf;
+    if (!guid && B * Nout > 0) return fail(PCF_E_BADARG, "pcf_backward_csr: guidance is null");
+    PCF_REQUIRE(inv_idx_len >= N + 1, "pcf_backward_csr: inverse_neighbor_idx size must be >= N + 1 (got %d, N=%d)",
+                inv_idx_len, N);
+    PCF_REQUIRE(inv_idx && (inv_len == 0 || (inv_neighbors && inv_k)), "pcf_backward_csr: null inverse index");
+    PCF_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= pcf_hip_pcf_backward_csr_workspace_bytes(B, Nout, K, Ci),
+                "pcf_backward_csr: workspace too small or misaligned");
+    PCF_REQUIRE(grad_x || (long long)B * N * Ci == 0, "pcf_backward_csr: grad_x is null");
+    hipStream_t s = (hipStream_t)stream;
+    float* contrib = static_cast<float*>(workspace);
+    if (B * Nout == 0) {
+        if ((size_t)B * N * Ci) (void)hipMemsetAsync(grad_x, 0, (size_t)B * N * Ci * 4, s);
+        return ok();
+    }
+    if (int e = aggregate_backward(grad_out, x, idx, guid, w, nullptr, nullptr, contrib, grad_guid, grad_w, nullptr, B, N,
+                                   Nout, K, Ci, 0, Cm, H, s))
+        return e;
+    return csr_reduce(contrib, inv_neighbors, inv_k, inv_idx, grad_x, B, N, Nout, K, Ci, inv_len, inv_idx_len, s);
+}
+
 }  // extern "C"

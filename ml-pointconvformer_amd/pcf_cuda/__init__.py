@@ -32,7 +32,7 @@ import torch
 __all__ = [
     'pcf_forward', 'pcf_backward', 'pconv_forward', 'pconv_backward', 'pconv_linear_forward',
     'pconv_linear_backward', 'pconv_linear_opt_backward', 'compute_knn_inverse',
-    'pconv_linear_cutlass_forward', 'knn_packed', 'gemm_nt', 'library_path', 'version',
+    'pconv_linear_cutlass_forward', 'pcf_backward_csr', 'knn_packed', 'gemm_nt', 'library_path', 'version',
 ]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -59,6 +59,8 @@ _version = _sig('pcf_hip_version', [], ctypes.c_char_p)
 _last_error = _sig('pcf_hip_last_error', [], ctypes.c_char_p)
 _pcf_fwd = _sig('pcf_hip_pcf_forward', [_P] * 5 + [_I] * 7 + [_P])
 _pcf_bwd = _sig('pcf_hip_pcf_backward', [_P] * 8 + [_I] * 7 + [_P])
+_pcf_bwd_csr_ws = _sig('pcf_hip_pcf_backward_csr_workspace_bytes', [_I] * 4, _Z)
+_pcf_bwd_csr = _sig('pcf_hip_pcf_backward_csr', [_P] * 12 + [_Z] + [_I] * 9 + [_P])
 _pconv_fwd = _sig('pcf_hip_pconv_forward', [_P] * 5 + [_I] * 7 + [_P])
 _pconv_bwd = _sig('pcf_hip_pconv_backward', [_P] * 8 + [_I] * 7 + [_P])
 _pl_fwd = _sig('pcf_hip_pconv_linear_forward', [_P] * 8 + [_I] * 8 + [_P])
@@ -183,6 +185,33 @@ def pcf_backward(grad_output, input, neighbor_inds, guidance, weights):
     with torch.cuda.device(dev):
         _call(_pcf_bwd, _ptr(grad_output), _ptr(input), _ptr(neighbor_inds), _ptr(guidance), _ptr(weights),
               _ptr(grad_input), _ptr(grad_guidance), _ptr(grad_weights), B, N, Nout, K, Ci, Cm, H, _stream(dev))
+    return [grad_input, grad_guidance, grad_weights]
+
+
+def pcf_backward_csr(grad_output, input, inverse_neighbor, inverse_neighbor_k, inverse_neighbor_idx, neighbor_inds,
+                     guidance, weights):
+    """pcf_backward with a deterministic, atomic-free grad_input: gather-reduce over the inverse CSR
+    that compute_knn_inverse built for `neighbor_inds` (not in the reference's module)."""
+    _floats(grad_output=grad_output, input=input, guidance=guidance, weights=weights)
+    _check_input(neighbor_inds, 'neighbor_inds', torch.int64)
+    _check_input(inverse_neighbor, 'inverse_neighbor', torch.int32)
+    _check_input(inverse_neighbor_k, 'inverse_neighbor_k', torch.uint8)
+    _check_input(inverse_neighbor_idx, 'inverse_neighbor_idx', torch.int32)
+    B, N, Nout, K, Ci, Cm = _dims(input, neighbor_inds, weights)
+    H = guidance.shape[3]
+    if grad_output.numel() != B * Nout * Ci * Cm:
+        raise RuntimeError('pcf_cuda: grad_output must be [B,Nout,C_in*C_mid]')
+    dev = _same_device(grad_output, input, neighbor_inds, guidance, weights, inverse_neighbor)
+    grad_input = torch.empty_like(input)
+    grad_guidance = torch.empty_like(guidance)
+    grad_weights = torch.empty_like(weights)
+    nbytes = _pcf_bwd_csr_ws(B, Nout, K, Ci)
+    ws = _workspace(nbytes, dev)
+    with torch.cuda.device(dev):
+        _call(_pcf_bwd_csr, _ptr(grad_output), _ptr(input), _ptr(inverse_neighbor), _ptr(inverse_neighbor_k),
+              _ptr(inverse_neighbor_idx), _ptr(neighbor_inds), _ptr(guidance), _ptr(weights), _ptr(grad_input),
+              _ptr(grad_guidance), _ptr(grad_weights), ws.data_ptr(), nbytes, B, N, Nout, K, Ci, Cm, H,
+              inverse_neighbor.shape[1], inverse_neighbor_idx.shape[1], _stream(dev))
     return [grad_input, grad_guidance, grad_weights]
 
 

@@ -36,26 +36,32 @@ import pcf_fused
 # operator boundary (layer_utils.py:42-173)
 # --------------------------------------------------------------------------------------------------
 class PCFFunction(torch.autograd.Function):
-    """Guided aggregate.  (layer_utils.py:89-106)"""
+    """Guided aggregate.  (layer_utils.py:89-106)  When the caller hands over the inverse CSR of the
+    neighbour table, grad_input is a deterministic gather-reduce instead of float atomics."""
 
     @staticmethod
-    def forward(ctx, input_feat, neighbor_inds, guidance, weightnet):
+    def forward(ctx, input_feat, neighbor_inds, guidance, weightnet, inv_neighbors=None, inv_k=None, inv_idx=None):
         out = pcf_cuda.pcf_forward(input_feat, neighbor_inds, guidance, weightnet)
-        ctx.save_for_backward(input_feat, neighbor_inds, guidance, weightnet)
+        ctx.save_for_backward(input_feat, neighbor_inds, guidance, weightnet, inv_neighbors, inv_k, inv_idx)
         return out
 
     @staticmethod
     def backward(ctx, grad_output):
-        gi, gg, gw = pcf_cuda.pcf_backward(grad_output.contiguous(), *ctx.saved_tensors)
-        return gi, None, gg, gw
+        input_feat, neighbor_inds, guidance, weightnet, inv_neighbors, inv_k, inv_idx = ctx.saved_tensors
+        if inv_idx is not None:
+            gi, gg, gw = pcf_cuda.pcf_backward_csr(grad_output.contiguous(), input_feat, inv_neighbors, inv_k, inv_idx,
+                                                   neighbor_inds, guidance, weightnet)
+        else:
+            gi, gg, gw = pcf_cuda.pcf_backward(grad_output.contiguous(), input_feat, neighbor_inds, guidance, weightnet)
+        return gi, None, gg, gw, None, None, None
 
 
 class PCF(nn.Module):
     """(layer_utils.py:109-124)"""
 
     @staticmethod
-    def forward(input_features, neighbor_inds, guidance, weightnet):
-        return PCFFunction.apply(input_features, neighbor_inds, guidance, weightnet)
+    def forward(input_features, neighbor_inds, guidance, weightnet, inv_neighbors=None, inv_k=None, inv_idx=None):
+        return PCFFunction.apply(input_features, neighbor_inds, guidance, weightnet, inv_neighbors, inv_k, inv_idx)
 
 
 class PConvFunction(torch.autograd.Function):
@@ -328,7 +334,10 @@ class PCFLayer(nn.Module):
             diff = pcf_fused.guidance_diff(guidance_x.contiguous(), nei_inds, feat_pe, use_max=strided)
             guidance_score = self.guidance_weight.forward_diff(diff)
         weights = self.weightnet(wn_in)
-        agg = PCF.forward(feats_x.contiguous(), nei_inds, guidance_score.contiguous(), weights.contiguous())
+        if not getattr(self.cfg, 'DETERMINISTIC_BACKWARD', False):
+            inv_neighbors = inv_k = inv_idx = None      # float atomics are ~25 % faster than the CSR reduce here
+        agg = PCF.forward(feats_x.contiguous(), nei_inds, guidance_score.contiguous(), weights.contiguous(),
+                          inv_neighbors, inv_k, inv_idx)
         new_feat = self.unary2(self.dropout(_linear_act(self.linear, agg, pcf_fused.ACT_RELU)))
         sparse_feats = pcf_fused.gather_max(dense_feats, nei_inds) if strided else dense_feats
         shortcut = self.unary_shortcut(sparse_feats)

@@ -247,6 +247,50 @@ def main():
         {'pe': (lay.pe_convs, 'out'), 'w': (lay.weightnet, 'out'), 'agg': (lay.linear, 'in'),
          'lin': (lay.linear.c, 'out')}, gen, dict(use_vi=1, use_pe=1))
 
+    # ---- whole segmentation model (backbone + decoder), 3 levels, tiny widths ----
+    mcfg = cfg(USE_PE=True, num_classes=5, dropout_fc=0.)
+    model_architecture.get_default_configs(mcfg, num_level=3, base_dim=16)
+    mcfg.feat_dim = [16, 32, 48]
+    mcfg.mid_dim = [4, 4, 4]
+    mcfg.mid_dim_back = 1
+    mcfg.guided_level = 0
+    mcfg.num_heads = 4
+    mcfg.resblocks = [0, 2, 1]
+    mcfg.resblocks_back = [0, 0, 0]
+    mcfg.PCONV_OPT = False
+    mcfg.USE_CUDA_KERNEL = False
+    torch.manual_seed(11)
+    net = model_architecture.PointConvFormer_Segmentation(mcfg)
+    net.train()
+    counts, K = [240, 90, 36], 8
+    xyz0, nrm0 = _cloud(counts[0], gen)
+    pcs, nrms = [xyz0], [nrm0]
+    for c in counts[1:]:
+        sel = torch.randperm(pcs[-1].shape[0], generator=gen)[:c]
+        pcs.append(pcs[-1][sel])
+        nrms.append(nrms[-1][sel])
+    e_self = [_knn(p, p, K)[None] for p in pcs]
+    e_fwd = [_knn(pcs[l], pcs[l + 1], K)[None] for l in range(len(pcs) - 1)]
+    e_prop = [_knn(pcs[l + 1], pcs[l], K)[None] for l in range(len(pcs) - 1)]
+    feats = torch.randn(1, counts[0], 3, generator=gen).requires_grad_(True)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    out = net(feats, [p[None] for p in pcs], e_self, e_fwd, e_prop, [n[None] for n in nrms])
+    gup = torch.randn(out.shape, generator=gen)
+    out.backward(gup)
+    blobs = {'out': out, 'gup': gup, 'in.features': feats, 'gin.features': feats.grad}
+    for l in range(len(pcs)):
+        blobs[f'in.xyz{l}'] = pcs[l]
+        blobs[f'in.nrm{l}'] = nrms[l]
+        blobs[f'in.edges_self{l}'] = e_self[l]
+    for l in range(len(pcs) - 1):
+        blobs[f'in.edges_forward{l}'] = e_fwd[l]
+        blobs[f'in.edges_propagate{l}'] = e_prop[l]
+    for k, v in sd.items():
+        blobs['sd.' + k] = v
+    for k, p_ in net.named_parameters():
+        blobs['gsd.' + k] = p_.grad
+    _save('model_seg3', blobs)
+
     # ---- VI transform alone, including a zero offset (self edge) ----
     import layer_utils
     N, K = 96, 16

@@ -314,3 +314,65 @@ def test_split_guidance_first_layer(device, K, bn):
     if bn:
         torch.testing.assert_close(bnm.weight.grad.cpu(), gamr.grad.float(), rtol=3e-4, atol=3e-4 * sc)
         torch.testing.assert_close(bnm.bias.grad.cpu(), betr.grad.float(), rtol=3e-4, atol=3e-4 * sc)
+
+
+def _model_cfg(opt):
+    import pcf_model
+    c = pcf_model.Config(USE_PE=True, num_classes=5, PCONV_OPT=opt, USE_CUDA_KERNEL=True)
+    pcf_model.get_default_configs(c, num_level=3, base_dim=16)
+    c.update(feat_dim=[16, 32, 48], mid_dim=[4, 4, 4], mid_dim_back=1, guided_level=0, num_heads=4,
+             resblocks=[0, 2, 1], resblocks_back=[0, 0, 0])
+    return c
+
+
+def _opt_key_map(net):
+    """my PCONV_OPT=True parameter / buffer names -> the names the reference uses with PCONV_OPT=False
+    (layers.py:591-602: `pconv_linear_opt.linear` + `bn` versus `linear.c` + `linear.bn`)."""
+    m = {}
+    for name, mod in net.named_modules():
+        if hasattr(mod, 'pconv_linear_opt'):
+            pre = name + '.'
+            for t in ('weight', 'bias'):
+                m[pre + 'pconv_linear_opt.linear.' + t] = pre + 'linear.c.' + t
+            if hasattr(mod, 'bn'):
+                for t in ('weight', 'bias', 'running_mean', 'running_var', 'num_batches_tracked'):
+                    m[pre + 'bn.' + t] = pre + 'linear.bn.' + t
+    return m
+
+
+@pytest.mark.parametrize('opt', [False, True])
+def test_segmentation_model_matches_reference(device, opt):
+    """The whole PointConvFormer_Segmentation graph (PointConv + StridePE level 0, strided and plain
+    PCFLayers, TransposePE decoder, head) against the reference model's golden: logits, feature gradient
+    and all parameter gradients; PCONV_OPT=True additionally routes the PointConv family through the
+    fused aggregate+linear op with the CSR backward."""
+    import pcf_model
+    import knn_post_dataloader_utils as U
+    g = load_golden('model_seg3')
+    net = pcf_model.PointConvFormer_Segmentation(_model_cfg(opt))
+    kmap = _opt_key_map(net) if opt else {}
+    ref_sd = split(g, 'sd.')
+    net.load_state_dict({k: ref_sd[kmap.get(k, k)] for k in net.state_dict()}, strict=True)
+    net.to(device).train()
+    L = 3
+    pcs = [g[f'in.xyz{l}'][None].to(device) for l in range(L)]
+    nrms = [g[f'in.nrm{l}'][None].to(device) for l in range(L)]
+    es = [g[f'in.edges_self{l}'].to(device) for l in range(L)]
+    ef = [g[f'in.edges_forward{l}'].to(device) for l in range(L - 1)]
+    ep = [g[f'in.edges_propagate{l}'].to(device) for l in range(L - 1)]
+    feats = g['in.features'].to(device).requires_grad_(True)
+    inv = U.compute_knn_inverse(pcs, es, ef, ep) if opt else (None, None, None)
+    out = net(feats, pcs, es, ef, ep, nrms, *inv)
+    torch.testing.assert_close(out.cpu(), g['out'], **TOL)
+    out.backward(g['gup'].to(device))
+    torch.testing.assert_close(feats.grad.cpu(), g['gin.features'], rtol=2e-3, atol=2e-3)
+    want = split(g, 'gsd.')
+    bad = []
+    for name, p in net.named_parameters():
+        ref_name = kmap.get(name, name)
+        ref = want[ref_name]
+        zero_grad_bias = ref_name.endswith('c.bias') and ref_name[:-6] + 'bn.weight' in want
+        scale = max(1.0, float(ref.abs().max()))
+        if not torch.allclose(p.grad.cpu(), ref, rtol=2e-3, atol=(5e-3 if zero_grad_bias else 2e-3) * scale):
+            bad.append((name, float((p.grad.cpu() - ref).abs().max()), scale))
+    assert not bad, bad[:8]

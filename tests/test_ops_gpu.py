@@ -337,3 +337,19 @@ def test_full_size_adjoint_and_linearity(device):
     rows = torch.tensor([0, 1, 39999, 79999])
     sub = O.pcf_forward(x.cpu(), idx.cpu()[:, rows], guid.cpu()[:, rows], w.cpu()[:, rows])
     torch.testing.assert_close(out.cpu()[:, rows], sub, **TOL)
+
+
+@pytest.mark.parametrize('shape', PCF_SHAPES[:4])
+def test_pcf_backward_csr(device, shape):
+    """grad_x by CSR gather-reduce: equal to the oracle, and bitwise reproducible."""
+    import pcf_cuda
+    B, N, Nout, K, Ci, Cm, H = shape
+    x, idx, guid, w, _ = _case(B, N, Nout, K, Ci, 0, Cm, H, seed=sum(shape) + 1)
+    d = lambda t: t.to(device)
+    gout = torch.randn(B, Nout, Ci * Cm, generator=torch.Generator().manual_seed(7))
+    inv = pcf_cuda.compute_knn_inverse(d(idx), N)
+    got = pcf_cuda.pcf_backward_csr(d(gout), d(x), *inv, d(idx), d(guid), d(w))
+    for a, b in zip(got, O.pcf_backward(gout, x, idx, guid, w)):
+        torch.testing.assert_close(a.cpu(), b, **TOL)
+    again = pcf_cuda.pcf_backward_csr(d(gout), d(x), *inv, d(idx), d(guid), d(w))
+    assert torch.equal(again[0], got[0])
