@@ -98,16 +98,79 @@ def cpu_baseline(state_dict, xyz, nrm, feats, idx, iters=3):
             f'iterations, median {med * 1e3:.0f} ms; oracle/pcf_oracle.py:pcf_layer on torch CPU'}
 
 
+LITE_YAML = dict(   # configs/configPCF_10cm_lite.yaml (model + training keys on the GPU path)
+    BATCH_NORM=True, USE_XYZ=True, USE_PE=True, point_dim=3, num_level=5, grid_size=[0.1, 0.2, 0.4, 0.8, 1.6],
+    base_dim=64, feat_dim=[64, 128, 192, 256, 384], mid_dim=[4, 4, 4, 4, 4], mid_dim_back=1, guided_level=0,
+    num_heads=8, resblocks=[0, 3, 3, 3, 3], resblocks_back=[0, 0, 0, 0, 0], K_self=[16] * 5, K_forward=[16] * 5,
+    K_propagate=[16] * 5, num_classes=20, label_smoothing=0.2, learning_rate=0.02, adamw_decay=0.05,
+    ignore_label=-100, drop_path_rate=0., dropout_rate=0., dropout_fc=0., layer_norm_guidance=False)
+
+
+def bench_train(args):
+    """Secondary workload: training iterations/s of the configPCF_10cm_lite model on synthetic 40k-point
+    scenes (BASELINE.json configs[1]); a step = post-kNN + inverse CSR + forward + CE loss + backward +
+    clip_grad_norm_ + AdamW step on one packed batch per GPU."""
+    import pcf_dist
+    rank, world, local_rank, dev = pcf_dist.setup('nccl')
+    import pcf_model
+    import pcf_train
+    cfg = pcf_model.Config(LITE_YAML)
+    pcf_model.get_default_configs(cfg, num_level=cfg.num_level, base_dim=cfg.base_dim)
+    cfg.PCONV_OPT, cfg.USE_CUDA_KERNEL = True, True
+    torch.manual_seed(1)
+    net = pcf_model.PointConvFormer_Segmentation(cfg).to(dev).train()
+    model = pcf_dist.wrap_ddp(net, dev)
+    opt = torch.optim.AdamW(net.parameters(), lr=cfg.learning_rate, weight_decay=cfg.adamw_decay)
+    crit = torch.nn.CrossEntropyLoss(ignore_index=cfg.ignore_label, label_smoothing=cfg.label_smoothing).to(dev)
+    # a small pool of distinct packed batches, rotated, so the kNN / CSR work is real every step
+    pool = []
+    for b in range(2):
+        scenes = [pcf_train.synthetic_scene(args.points, cfg.grid_size, seed=1000 * (rank + 1) + 10 * b + i, device=dev)
+                  for i in range(args.scenes)]
+        pool.append(pcf_train.pack_batch(scenes))
+    n_pts = sum(pool[0][4][0])
+
+    def step(i):
+        return pcf_train.training_iteration(model, opt, crit, cfg, pool[i % len(pool)])
+
+    for i in range(args.warmup):
+        step(i)
+    pcf_dist.fence(dev)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(i)
+    pcf_dist.fence(dev)
+    elapsed = pcf_dist.max_over_ranks(time.perf_counter() - t0, dev)
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'ScanNet-10cm (lite) train iters/sec, synthetic scenes', 'value': round(args.steps / elapsed, 3),
+            'unit': 'iters/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'points_per_s': round(world * n_pts * args.steps / elapsed, 1), 'final_loss': round(float(loss), 4),
+            'config': {'workload': f'configPCF_10cm_lite model ({sum(p.numel() for p in net.parameters())} params), '
+                                   f'{args.scenes} scenes x ~{args.points} points per GPU per iteration '
+                                   f'({n_pts} level-0 points, levels {pool[0][4]}), kNN + CSR + fwd + bwd + AdamW',
+                       'parallelism': f'dp{world}', 'sync_bn': False}}), flush=True)
+    pcf_dist.shutdown()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--points', type=int, default=N_POINTS)
+    ap.add_argument('--points', type=int, default=None)
+    ap.add_argument('--workload', choices=['layer', 'train'], default='layer')
+    ap.add_argument('--scenes', type=int, default=4, help='scenes per GPU per iteration (train workload)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--deterministic', action='store_true',
                     help='grad_x by CSR gather-reduce (bitwise reproducible) instead of float atomics')
     args = ap.parse_args()
+    if args.points is None:
+        args.points = N_POINTS if args.workload == 'layer' else 40000
+    if args.workload == 'train':
+        return bench_train(args)
 
     import pcf_dist
     rank, world, local_rank = pcf_dist.env_rank()

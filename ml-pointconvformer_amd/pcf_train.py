@@ -1,0 +1,95 @@
+"""Synthetic multi-resolution scenes and one training iteration, as the reference's loop runs it.
+
+The dataset side of the reference (ScanNet files, augmentation, CPU voxelisation in dataloader
+workers) is out of scope; what is reproduced here is the *shape* of what reaches the GPU and the
+sequence of device work per iteration (``train_ScanNet_DDP_WarmUP.py:376-424``):
+
+    post-kNN over the packed batch  (compute_knn_packed + prepare)          :382-383
+    inverse CSR of every edge set   (compute_knn_inverse, PCONV_OPT)         :401
+    forward, cross-entropy, backward, clip_grad_norm_(10), optimizer step   :404-424
+
+Scenes are points on a gently folded surface (indoor scans are 2-D manifolds: each halving of the
+resolution keeps about a quarter of the points), voxel-grid subsampled on the GPU once per level with
+the YAML's ``grid_size`` ratios, packed over the batch exactly like ``datasetCommon.py:348-379``
+([1, sum_i N_i, C] tensors + per-sample counts).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+import knn_post_dataloader_utils as knn_utils
+
+
+def _grid_subsample(xyz, grid):
+    """One point per occupied voxel of edge `grid` (the first in index order) -> indices, ascending."""
+    v = torch.floor(xyz / grid).to(torch.int64)
+    v = v - v.min(0, keepdim=True)[0]
+    dims = v.max(0)[0] + 1
+    key = (v[:, 0] * dims[1] + v[:, 1]) * dims[2] + v[:, 2]
+    order = torch.argsort(key, stable=True)
+    ks = key[order]
+    first = torch.ones_like(ks, dtype=torch.bool)
+    first[1:] = ks[1:] != ks[:-1]
+    return torch.sort(order[first])[0]
+
+
+def synthetic_scene(n_points, grid_sizes, seed, device, n_features=3, n_classes=20):
+    """One scene: per-level xyz / unit normals, level-0 features and labels.  The level-0 cloud has about
+    `n_points` points after voxelisation at grid_sizes[0]."""
+    g = torch.Generator().manual_seed(seed)
+    side = grid_sizes[0] * math.sqrt(n_points) * 1.05           # ~1 point per level-0 voxel of the sheet
+    m = int(n_points * 1.6)
+    xy = torch.rand(m, 2, generator=g) * side
+    fx, fy = 1.1, 0.7
+    z = 0.35 * torch.sin(fx * xy[:, 0]) + 0.25 * torch.cos(fy * xy[:, 1])
+    xyz = torch.stack([xy[:, 0], xy[:, 1], z], 1).to(device)
+    dzdx = 0.35 * fx * torch.cos(fx * xy[:, 0])
+    dzdy = -0.25 * fy * torch.sin(fy * xy[:, 1])
+    nrm = torch.nn.functional.normalize(torch.stack([-dzdx, -dzdy, torch.ones_like(dzdx)], 1), dim=1).to(device)
+    keep = _grid_subsample(xyz, grid_sizes[0])[:n_points]
+    levels_xyz, levels_nrm = [xyz[keep]], [nrm[keep]]
+    for gs in grid_sizes[1:]:
+        sel = _grid_subsample(levels_xyz[-1], gs)
+        levels_xyz.append(levels_xyz[-1][sel])
+        levels_nrm.append(levels_nrm[-1][sel])
+    n0 = levels_xyz[0].shape[0]
+    feats = torch.randn(n0, n_features, generator=g).to(device)
+    labels = torch.randint(0, n_classes, (n0,), generator=g).to(device)
+    return dict(xyz=levels_xyz, nrm=levels_nrm, features=feats, labels=labels)
+
+
+def pack_batch(scenes):
+    """Scenes -> the packed batch the collate function emits: features [1,sumN0,C], pointclouds /
+    norms lists of [1,sumN_l,3], target [sumN0], points_stored [level][sample]."""
+    L = len(scenes[0]['xyz'])
+    pointclouds = [torch.cat([s['xyz'][l] for s in scenes])[None].contiguous() for l in range(L)]
+    norms = [torch.cat([s['nrm'][l] for s in scenes])[None].contiguous() for l in range(L)]
+    features = torch.cat([s['features'] for s in scenes])[None].contiguous()
+    target = torch.cat([s['labels'] for s in scenes])
+    points_stored = [[int(s['xyz'][l].shape[0]) for s in scenes] for l in range(L)]
+    return features, pointclouds, target, norms, points_stored
+
+
+def build_edges(cfg, pointclouds, points_stored):
+    """post-kNN + inverse CSR for one packed batch (train_ScanNet_DDP_WarmUP.py:382-383,401)."""
+    es, ef, ep = knn_utils.prepare(*knn_utils.compute_knn_packed(pointclouds, points_stored, cfg.K_self, cfg.K_forward,
+                                                                 cfg.K_propagate))
+    inv = (None, None, None)
+    if cfg.PCONV_OPT:
+        inv = knn_utils.compute_knn_inverse(pointclouds, es, ef, ep)
+    return es, ef, ep, inv
+
+
+def training_iteration(model, optimizer, criterion, cfg, batch, edges=None):
+    """One optimisation step on one packed batch; returns the loss tensor (no host sync)."""
+    features, pointclouds, target, norms, points_stored = batch
+    es, ef, ep, inv = edges if edges is not None else build_edges(cfg, pointclouds, points_stored)
+    pred = model(features, pointclouds, es, ef, ep, norms, *inv)
+    loss = criterion(pred.reshape(-1, cfg.num_classes), target)
+    loss.backward()
+    torch.nn.utils.clip_grad_norm_(model.parameters(), 10)
+    optimizer.step()
+    optimizer.zero_grad(set_to_none=True)
+    return loss.detach()
