@@ -141,6 +141,13 @@ int pcf_hip_knn_inverse(const int64_t* idx, int32_t* inv_neighbors, uint8_t* inv
 int pcf_hip_knn(const float* ref, const float* query, const int32_t* ref_off, const int32_t* query_off,
                 int n_seg, int max_queries_per_seg, int K, int64_t* out, void* stream);
 
+/* Same contract and bit-identical output as pcf_hip_knn, through a uniform-grid index over the reference
+ * points (cell sort + ring search); the engine for large clouds.  n_ref / n_query are the packed totals. */
+size_t pcf_hip_knn_grid_workspace_bytes(int n_ref, int n_seg);
+int pcf_hip_knn_grid(const float* ref, const float* query, const int32_t* ref_off, const int32_t* query_off,
+                     int n_seg, int n_ref, int n_query, int K, int64_t* out, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
 /* ---- per-edge helpers around the aggregate ---------------------------------------------------
  * replace index_points (layer_utils.py:13-30) and its index_put_ backward: */
 /* out[b,s,:] = table[b, idx[b,s], :]   table [B,N,C], idx [B,S] i64 (S = M*K for a neighbour table) */

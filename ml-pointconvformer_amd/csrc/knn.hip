@@ -164,6 +164,19 @@ __global__ __launch_bounds__(BLOCK) void scan_write_kernel(const int32_t* __rest
     }
 }
 
+// out[i] = sum of counts[0..i) for i in [0, n]; chunk_tmp holds ceil(n / 1024) ints.  (also used by knn_grid.hip)
+int exclusive_scan_i32(const int32_t* counts, int32_t* chunk_tmp, int32_t* out, int n, hipStream_t s) {
+    if (n <= 0) {
+        hipError_t e = hipMemsetAsync(out, 0, 4, s);
+        return e == hipSuccess ? ok() : fail(PCF_E_LAUNCH, "scan: %s", hipGetErrorString(e));
+    }
+    const int nchunks = ceil_div(n, SCAN_CHUNK);
+    hipLaunchKernelGGL(scan_chunk_sums_kernel, dim3(nchunks), dim3(BLOCK), 0, s, counts, chunk_tmp, n);
+    hipLaunchKernelGGL(scan_chunk_offsets_kernel, dim3(1), dim3(BLOCK), 0, s, chunk_tmp, nchunks);
+    hipLaunchKernelGGL(scan_write_kernel, dim3(nchunks), dim3(BLOCK), 0, s, counts, chunk_tmp, out, n);
+    return check_launch("exclusive scan");
+}
+
 __global__ __launch_bounds__(BLOCK) void csr_fill_kernel(const int64_t* __restrict__ idx,
                                                          const int32_t* __restrict__ inv_idx,
                                                          int32_t* __restrict__ cursor, uint32_t* __restrict__ keys,

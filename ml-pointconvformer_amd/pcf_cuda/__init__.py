@@ -71,6 +71,8 @@ _plo_bwd = _sig('pcf_hip_pconv_linear_opt_backward', [_P] * 16 + [_Z] + [_I] * 1
 _inv_ws = _sig('pcf_hip_knn_inverse_workspace_bytes', [_I] * 4, _Z)
 _inv = _sig('pcf_hip_knn_inverse', [_P] * 5 + [_Z] + [_I] * 4 + [_P])
 _knn = _sig('pcf_hip_knn', [_P] * 4 + [_I] * 3 + [_P] * 2)
+_knn_grid_ws = _sig('pcf_hip_knn_grid_workspace_bytes', [_I, _I], _Z)
+_knn_grid = _sig('pcf_hip_knn_grid', [_P] * 4 + [_I] * 4 + [_P, _P, _Z, _P])
 _gemm_nt = _sig('pcf_hip_gemm_nt', [_P] * 4 + [_I] * 3 + [_P])
 
 
@@ -369,12 +371,17 @@ def compute_knn_inverse(neighbor_inds, total_points):
 
 
 # ---- extras beyond the reference's nine (used by knn_post_dataloader_utils and the tests) --------
-def knn_packed(ref, query, ref_offsets, query_offsets, K):
+KNN_GRID_MIN_REFS = 2048     # below this the brute-force kernel is as fast and needs no index
+
+
+def knn_packed(ref, query, ref_offsets, query_offsets, K, method='auto'):
     """K nearest refs (own sample only) for every query of a packed batch.
 
     ref [Nr,3] f32, query [Nq,3] f32 device tensors; ref_offsets / query_offsets int32 [S+1]
     device tensors of per-sample prefix offsets.  Returns int64 [Nq,K] of packed ref indices,
-    (distance, index) ascending; -1 where a sample has fewer than K refs."""
+    (distance, index) ascending; -1 where a sample has fewer than K refs.  ``method``: 'brute'
+    (tiled brute force), 'grid' (uniform-grid index) or 'auto' (grid from 2048 reference points up);
+    both engines return bit-identical results."""
     _floats(ref=ref, query=query)
     _check_input(ref_offsets, 'ref_offsets', torch.int32)
     _check_input(query_offsets, 'query_offsets', torch.int32)
@@ -385,11 +392,20 @@ def knn_packed(ref, query, ref_offsets, query_offsets, K):
         raise RuntimeError('pcf_cuda: offset tensors must both be [num_samples+1]')
     dev = _same_device(ref, query, ref_offsets, query_offsets)
     out = torch.empty(query.shape[0], K, dtype=torch.int64, device=dev)
-    # the widest sample bounds the grid; a host-side upper bound avoids a device->host sync
-    max_q = query.shape[0]
+    if method not in ('auto', 'brute', 'grid'):
+        raise ValueError(f'knn_packed: unknown method {method!r}')
+    n_ref, n_query = ref.shape[0], query.shape[0]
+    use_grid = method == 'grid' or (method == 'auto' and n_ref >= KNN_GRID_MIN_REFS)
     with torch.cuda.device(dev):
-        _call(_knn, _ptr(ref), _ptr(query), ref_offsets.data_ptr(), query_offsets.data_ptr(), S, max_q, int(K),
-              _ptr(out), _stream(dev))
+        if use_grid:
+            nbytes = _knn_grid_ws(n_ref, S)
+            ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=dev)
+            _call(_knn_grid, _ptr(ref), _ptr(query), ref_offsets.data_ptr(), query_offsets.data_ptr(), S, n_ref, n_query,
+                  int(K), _ptr(out), ws.data_ptr(), nbytes, _stream(dev))
+        else:
+            # the widest sample bounds the launch grid; a host-side upper bound avoids a device->host sync
+            _call(_knn, _ptr(ref), _ptr(query), ref_offsets.data_ptr(), query_offsets.data_ptr(), S, n_query, int(K),
+                  _ptr(out), _stream(dev))
     return out
 
 

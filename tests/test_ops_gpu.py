@@ -353,3 +353,53 @@ def test_pcf_backward_csr(device, shape):
         torch.testing.assert_close(a.cpu(), b, **TOL)
     again = pcf_cuda.pcf_backward_csr(d(gout), d(x), *inv, d(idx), d(guid), d(w))
     assert torch.equal(again[0], got[0])
+
+
+def _surface(n, rng, side=20.0):
+    xy = rng.random((n, 2), dtype=np.float32) * side
+    z = (0.35 * np.sin(1.1 * xy[:, 0]) + 0.25 * np.cos(0.7 * xy[:, 1])).astype(np.float32)
+    return np.concatenate([xy, z[:, None]], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize('case', ['volume', 'surface', 'cross', 'plane', 'line', 'duplicates', 'tiny_segments', 'k40'])
+def test_knn_grid_equals_bruteforce(device, case):
+    """The grid engine returns exactly what the brute-force engine returns (which the oracle pins):
+    volumes, folded sheets, exactly planar / collinear clouds (degenerate grid axes), heavy
+    duplicates (ties by index), queries outside the reference box, tiny samples inside a packed batch."""
+    import pcf_cuda
+    rng = np.random.default_rng(abs(hash(case)) % 1000)
+    K = 16
+    if case == 'volume':
+        ref = rng.random((30000, 3), dtype=np.float32); qry = ref; roff = qoff = [0, 12000, 30000]
+    elif case == 'surface':
+        ref = _surface(40000, rng); qry = ref; roff = qoff = [0, 40000]
+    elif case == 'cross':
+        ref = _surface(9000, rng); qry = _surface(30000, rng, side=24.0) - 2.0; roff = [0, 4000, 9000]; qoff = [0, 10000, 30000]
+    elif case == 'plane':
+        ref = rng.random((20000, 3), dtype=np.float32); ref[:, 2] = 0.5; qry = ref; roff = qoff = [0, 20000]
+    elif case == 'line':
+        ref = np.zeros((6000, 3), np.float32); ref[:, 0] = rng.random(6000, dtype=np.float32) * 100; qry = ref; roff = qoff = [0, 6000]
+    elif case == 'duplicates':
+        base = rng.random((500, 3), dtype=np.float32); ref = np.repeat(base, 20, 0); rng.shuffle(ref); qry = ref[:3000]; roff = [0, 10000]; qoff = [0, 3000]
+    elif case == 'tiny_segments':
+        ref = rng.random((5000, 3), dtype=np.float32); qry = ref; roff = qoff = [0, 3, 20, 4000, 4000, 5000]
+    else:
+        ref = rng.random((8000, 3), dtype=np.float32); qry = rng.random((5000, 3), dtype=np.float32) * 1.5 - 0.25; roff = [0, 8000]; qoff = [0, 5000]; K = 40
+    t = lambda a, dt=torch.float32: torch.as_tensor(np.asarray(a), dtype=dt).to(device)
+    args = (t(ref), t(qry), t(roff, torch.int32), t(qoff, torch.int32), K)
+    brute = pcf_cuda.knn_packed(*args, method='brute').cpu().numpy()
+    grid = pcf_cuda.knn_packed(*args, method='grid').cpu().numpy()
+    np.testing.assert_array_equal(grid, brute)
+
+
+def test_knn_grid_bit_exact_vs_c_oracle_80k(device):
+    """BASELINE size: 80 000 points, K = 16, against the C oracle (oracle/knn_ref.c), ~15 s of CPU."""
+    from oracle import knn_c
+    import pcf_cuda
+    rng = np.random.default_rng(80)
+    ref = rng.random((80000, 3), dtype=np.float32)
+    off = torch.tensor([0, 80000], dtype=torch.int32, device=device)
+    got = pcf_cuda.knn_packed(torch.from_numpy(ref).to(device), torch.from_numpy(ref).to(device), off, off, 16)
+    sub = np.arange(0, 80000, 16)                       # every 16th query keeps the oracle at seconds
+    want = knn_c.knn_packed(ref, ref[sub], [0, 80000], [0, len(sub)], 16)
+    np.testing.assert_array_equal(got.cpu().numpy()[sub], want)
