@@ -216,6 +216,24 @@ int pcf_hip_rowlin_backward_ex(const float* x, const float* dy, long long R, int
                                float* dgamma, float* dbeta, float* dgadd, void* workspace, size_t workspace_bytes,
                                void* stream);
 
+/* ---- wide point-level Linear_BN: BatchNorm (+activation) over the rows of [R, C], any C ------------
+ * replaces Linear_BN / UnaryBlock on [B,N,C] tensors wider than 64 channels (layer_utils.py:241-319;
+ * PCFLayer.linear layers.py:273-277,393; decoder linears layers.py:973-981): z = x.W^T + b comes from
+ * pcf_hip_gemm_nt, these kernels do the statistics, y = act(BN(z)) and its backward, and
+ * pcf_hip_linear_backward the three products dx = dz.W, dW = dz^T.x, db = colsum(dz) on the MFMA path. */
+size_t pcf_hip_bnact_workspace_bytes(long long R, int C);
+int pcf_hip_bnact_stats(const float* z, long long R, int C, float eps, float momentum, float* running_mean,
+                        float* running_var, float* mean_out, float* rstd_out, void* workspace,
+                        size_t workspace_bytes, void* stream);
+int pcf_hip_bnact_forward(const float* z, long long R, int C, const float* mean, const float* rstd,
+                          const float* gamma, const float* beta, int act, float* y, void* stream);
+int pcf_hip_bnact_backward(const float* z, const float* dy, long long R, int C, const float* mean, const float* rstd,
+                           const float* gamma, const float* beta, int batch_stats, int act, float* dz,
+                           float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
+size_t pcf_hip_linear_backward_workspace_bytes(long long R, int Cin, int Cout);
+int pcf_hip_linear_backward(const float* dz, const float* x, const float* W, long long R, int Cin, int Cout,
+                            float* dx, float* dW, float* db, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- guidance difference (query - key) --------------------------------------------------------
  * replaces layers.py:372-381 + layers.py:52-53: q = cat(index_points(guidance_x, nei), feat_pe),
  * key = q[:, :, :1] (self) or q.max(dim=2) (strided, use_max != 0), s = q - key.

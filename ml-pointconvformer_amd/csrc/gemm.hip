@@ -159,14 +159,28 @@ __global__ __launch_bounds__(BLOCK) void gemm_f32_kernel(const GemmArgs g) {
     }
 }
 
-// Sum split-K slabs: C[i] = sum_s slab[s][i]  (fixed order -> deterministic).
+// Sum split-K slabs: C[i] = sum_s slab[s][i] in a fixed order (deterministic).  Four slices of the slab
+// list per element, four loads in flight per lane.
 __global__ __launch_bounds__(BLOCK) void slab_sum_kernel(const float* __restrict__ slabs, float* __restrict__ C,
                                                          long long count, int splits) {
-    for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < count; i += (long long)gridDim.x * BLOCK) {
-        float acc = 0.f;
-        for (int s = 0; s < splits; ++s) acc += slabs[(size_t)s * count + i];
-        C[i] = acc;
+    __shared__ float sh[BLOCK];
+    const long long i = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
+    const int slice = threadIdx.x >> 6;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (i < count) {
+        int s = slice;
+        for (; s + 12 < splits; s += 16) {
+            a0 += slabs[(size_t)s * count + i];
+            a1 += slabs[(size_t)(s + 4) * count + i];
+            a2 += slabs[(size_t)(s + 8) * count + i];
+            a3 += slabs[(size_t)(s + 12) * count + i];
+        }
+        for (; s < splits; s += 4) a0 += slabs[(size_t)s * count + i];
     }
+    sh[threadIdx.x] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (threadIdx.x < 64 && i < count)
+        C[i] = (sh[threadIdx.x] + sh[64 + threadIdx.x]) + (sh[128 + threadIdx.x] + sh[192 + threadIdx.x]);
 }
 
 // Column sums of a [rows, cols] matrix in two deterministic stages (grad of the linear bias).
@@ -217,12 +231,12 @@ int choose_splits(int M, int N, int Kd) {
     const long long tiles = (long long)ceil_div(M, N <= 32 ? 128 : 64) * ceil_div(N, N <= 32 ? 32 : 64);
     long long want = (1024 + tiles - 1) / tiles;             // ~4 workgroups per CU overall
     const long long max_by_k = std::max(1, Kd / (GBK * 8));  // at least 8 K-steps per split
-    return (int)std::max<long long>(1, std::min<long long>(std::min<long long>(want, max_by_k), 512));
+    return (int)std::max<long long>(1, std::min<long long>(std::min<long long>(want, max_by_k), 128));
 }
 
 int slab_sum(const float* slabs, float* C, long long count, int splits, hipStream_t s) {
     if (count == 0) return ok();
-    const int grid = (int)std::min<long long>((count + BLOCK - 1) / BLOCK, 2048);
+    const int grid = (int)((count + 63) / 64);
     hipLaunchKernelGGL(slab_sum_kernel, dim3(grid), dim3(BLOCK), 0, s, slabs, C, count, splits);
     return check_launch("split-K slab sum");
 }

@@ -281,3 +281,98 @@ def guidance_diff(guidance_x, nei_inds, feat_pe, use_max):
     _floats(guidance_x=guidance_x, feat_pe=feat_pe)
     _check_input(nei_inds, 'nei_inds', torch.int64)
     return _GuidanceDiff.apply(guidance_x, nei_inds, feat_pe, bool(use_max))
+
+
+# --------------------------------------------------------------------------------------------------
+# wide point-level Linear (+BN) (+activation): MFMA contraction + column-wise BN kernels (csrc/bnact.hip)
+# --------------------------------------------------------------------------------------------------
+_gemm_nt_c = _sig('pcf_hip_gemm_nt', [_P] * 4 + [_I] * 3 + [_P])
+_bnact_ws = getattr(_lib, 'pcf_hip_bnact_workspace_bytes')
+_bnact_ws.argtypes = [_LL, _I]
+_bnact_ws.restype = _Z
+_bnact_stats = _sig('pcf_hip_bnact_stats', [_P, _LL, _I, _F, _F, _P, _P, _P, _P, _P, _Z, _P])
+_bnact_fwd = _sig('pcf_hip_bnact_forward', [_P, _LL, _I, _P, _P, _P, _P, _I, _P, _P])
+_bnact_bwd = _sig('pcf_hip_bnact_backward', [_P, _P, _LL, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _Z, _P])
+_linbwd_ws = getattr(_lib, 'pcf_hip_linear_backward_workspace_bytes')
+_linbwd_ws.argtypes = [_LL, _I, _I]
+_linbwd_ws.restype = _Z
+_linbwd = _sig('pcf_hip_linear_backward', [_P, _P, _P, _LL, _I, _I, _P, _P, _P, _P, _Z, _P])
+
+
+class _WideLinearBNAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, W, b, gamma, beta, running_mean, running_var, eps, momentum, training, act):
+        x, W, b = x.contiguous(), W.contiguous(), b.contiguous()
+        Cout, Cin = W.shape
+        R = x.numel() // Cin
+        dev = x.device
+        bn = gamma is not None
+        stream = _stream(dev)
+        z = torch.empty(*x.shape[:-1], Cout, dtype=torch.float32, device=dev)
+        mean = rstd = None
+        with torch.cuda.device(dev):
+            _call(_gemm_nt_c, _ptr(x), _ptr(W), _ptr(b), _ptr(z), R, Cout, Cin, stream)
+            if bn and training:
+                mean = torch.empty(Cout, dtype=torch.float32, device=dev)
+                rstd = torch.empty(Cout, dtype=torch.float32, device=dev)
+                nbytes = _bnact_ws(R, Cout)
+                ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                _call(_bnact_stats, _ptr(z), R, Cout, float(eps), float(momentum), _ptr(running_mean), _ptr(running_var),
+                      _ptr(mean), _ptr(rstd), ws.data_ptr(), nbytes, stream)
+            elif bn:
+                mean, rstd = running_mean, torch.rsqrt(running_var + eps)
+            if bn or act != ACT_NONE:
+                y = torch.empty_like(z)
+                _call(_bnact_fwd, _ptr(z), R, Cout, _ptr(mean), _ptr(rstd), _ptr(gamma) if bn else None,
+                      _ptr(beta) if bn else None, int(act), _ptr(y), stream)
+            else:
+                y = z
+        ctx.save_for_backward(x, W, z, gamma, beta, mean, rstd)
+        ctx.cfg = (bool(training), int(act), bn)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W, z, gamma, beta, mean, rstd = ctx.saved_tensors
+        training, act, bn = ctx.cfg
+        dy = dy.contiguous()
+        Cout, Cin = W.shape
+        R = x.numel() // Cin
+        dev = x.device
+        stream = _stream(dev)
+        dgamma = torch.empty_like(gamma) if bn else None
+        dbeta = torch.empty_like(beta) if bn else None
+        with torch.cuda.device(dev):
+            if bn or act != ACT_NONE:
+                dz = torch.empty_like(z)
+                nbytes = _bnact_ws(R, Cout)
+                ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                _call(_bnact_bwd, _ptr(z), _ptr(dy), R, Cout, _ptr(mean), _ptr(rstd), _ptr(gamma) if bn else None,
+                      _ptr(beta) if bn else None, 1 if training else 0, act, _ptr(dz), _ptr(dgamma), _ptr(dbeta),
+                      ws.data_ptr(), nbytes, stream)
+            else:
+                dz = dy
+            dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+            dW = torch.empty_like(W)
+            db = torch.empty(Cout, dtype=torch.float32, device=dev)
+            nbytes = _linbwd_ws(R, Cin, Cout)
+            ws2 = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            _call(_linbwd, _ptr(dz), _ptr(x), _ptr(W), R, Cin, Cout, _ptr(dx), _ptr(dW), _ptr(db), ws2.data_ptr(), nbytes, stream)
+        return dx, dW, db, dgamma, dbeta, None, None, None, None, None, None
+
+
+def wide_linear_bn_act(x, weight, bias, bn, act, training):
+    """Linear (+BatchNorm1d module `bn` or None) (+activation) for channel counts beyond the per-edge
+    engine's 64: MFMA contraction + column-wise BN kernels, fully on HIP."""
+    x, weight, bias = x.contiguous(), weight.contiguous(), bias.contiguous()
+    _floats(x=x, weight=weight, bias=bias)
+    if x.numel() // x.shape[-1] >= 2 ** 31:
+        raise RuntimeError('wide_linear_bn_act: more than 2^31 rows')
+    if bn is None:
+        return _WideLinearBNAct.apply(x, weight, bias, None, None, None, None, 0.0, 0.0, False, act)
+    use_batch = training or bn.running_mean is None
+    if training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    momentum = 0.1 if bn.momentum is None else bn.momentum
+    return _WideLinearBNAct.apply(x, weight, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, momentum,
+                                  use_batch, act)

@@ -175,9 +175,8 @@ class Linear_BN(nn.Module):
         """BN(x W^T + b), optionally followed by `act` (a pcf_fused.ACT_* code) in the same kernel."""
         if pcf_fused.rowlin_supported(self.c.in_features, self.c.out_features):
             return pcf_fused.linear_bn_act(x, self.c.weight, self.c.bias, self.bn, act, self.training)
-        y = self.c(x)                      # wide point-level layers: library GEMM + BatchNorm
-        y = self.bn(y.reshape(-1, y.shape[-1])).view(y.shape)
-        return _apply_act(y, act)
+        # wide point-level layers: fp32 MFMA contraction + column-wise BatchNorm kernels
+        return pcf_fused.wide_linear_bn_act(x, self.c.weight, self.c.bias, self.bn, act, self.training)
 
 
 def _apply_act(y, act):
@@ -196,7 +195,7 @@ def _linear_act(layer, x, act):
         return layer(x, act)
     if pcf_fused.rowlin_supported(layer.in_features, layer.out_features):
         return pcf_fused.linear_bn_act(x, layer.weight, layer.bias, None, act, layer.training)
-    return _apply_act(layer(x), act)
+    return pcf_fused.wide_linear_bn_act(x, layer.weight, layer.bias, None, act, layer.training)
 
 
 class UnaryBlock(nn.Module):

@@ -376,3 +376,46 @@ def test_segmentation_model_matches_reference(device, opt):
         if not torch.allclose(p.grad.cpu(), ref, rtol=2e-3, atol=(5e-3 if zero_grad_bias else 2e-3) * scale):
             bad.append((name, float((p.grad.cpu() - ref).abs().max()), scale))
     assert not bad, bad[:8]
+
+
+@pytest.mark.parametrize('rows,cin,cout,act,bn,training', [
+    (5000, 256, 32, 1, True, True), (777, 416, 256, 1, True, True), (1200, 96, 192, 2, True, True),
+    (300, 1536, 192, 0, True, False), (640, 128, 20, 0, False, True), (1000, 70, 70, 3, True, True)])
+def test_wide_linear_bn_act_against_torch(device, rows, cin, cout, act, bn, training):
+    """MFMA contraction + column-wise BN kernels vs torch fp64 on the CPU: output, dx, dW, db, dgamma, dbeta,
+    running statistics."""
+    import copy
+    import pcf_fused
+    g = torch.Generator().manual_seed(rows + cin)
+    x = torch.randn(1, rows, cin, generator=g) + 0.2
+    lin = torch.nn.Linear(cin, cout)
+    bnm = torch.nn.BatchNorm1d(cout) if bn else None
+    if bn:
+        with torch.no_grad():
+            bnm.weight.copy_(torch.rand(cout, generator=g) + 0.5)
+            bnm.bias.copy_(torch.randn(cout, generator=g) * 0.2)
+            bnm.running_var.copy_(torch.rand(cout, generator=g) + 0.5)
+    lin_d, bn_d = copy.deepcopy(lin).to(device), (copy.deepcopy(bnm).to(device).train(training) if bn else None)
+    ref_lin, ref_bn = copy.deepcopy(lin).double(), (copy.deepcopy(bnm).double().train(training) if bn else None)
+    actf = {0: lambda t: t, 1: torch.relu, 2: lambda t: torch.nn.functional.leaky_relu(t, 0.1), 3: torch.sigmoid}[act]
+    xr = x.double().requires_grad_(True)
+    zz = ref_lin(xr)
+    if bn:
+        zz = ref_bn(zz.reshape(-1, cout)).view(zz.shape)
+    want = actf(zz)
+    up = torch.randn(want.shape, generator=g)
+    want.backward(up.double())
+    xd = x.to(device).requires_grad_(True)
+    got = pcf_fused.wide_linear_bn_act(xd, lin_d.weight, lin_d.bias, bn_d, act, training)
+    got.backward(up.to(device))
+    tol = dict(rtol=3e-4, atol=3e-4)
+    torch.testing.assert_close(got.cpu(), want.float(), **tol)
+    torch.testing.assert_close(xd.grad.cpu(), xr.grad.float(), **tol)
+    sc = max(1.0, float(ref_lin.weight.grad.abs().max()))
+    torch.testing.assert_close(lin_d.weight.grad.cpu(), ref_lin.weight.grad.float(), rtol=3e-4, atol=3e-4 * sc)
+    torch.testing.assert_close(lin_d.bias.grad.cpu(), ref_lin.bias.grad.float(), rtol=3e-4, atol=3e-3 * sc)
+    if bn:
+        torch.testing.assert_close(bn_d.weight.grad.cpu(), ref_bn.weight.grad.float(), rtol=3e-4, atol=3e-4 * sc)
+        torch.testing.assert_close(bn_d.bias.grad.cpu(), ref_bn.bias.grad.float(), rtol=3e-4, atol=3e-4 * sc)
+        torch.testing.assert_close(bn_d.running_mean.cpu(), ref_bn.running_mean.float(), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(bn_d.running_var.cpu(), ref_bn.running_var.float(), rtol=1e-5, atol=1e-6)
