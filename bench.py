@@ -262,9 +262,16 @@ def main():
         dom = max((k for k in cand if k in hip_ms), key=lambda k: hip_ms[k])
         bytes_per_launch = cand[dom][0] * n
         achieved = bytes_per_launch / (hip_ms[dom] * 1e-3) / 1e9
+        traffic = None     # HBM bytes per launch from the PMC counters (profiles/r01_pmc_traffic.json), same shape only
+        try:
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
+            if pmc['shape'] == {'N': n, 'K': K_NEI, 'Ci': Ci, 'Cm': C_MID, 'H': HEADS}:
+                traffic = pmc['kernels'].get(cand[dom][1], {}).get('traffic_bytes')
+        except (OSError, ValueError, KeyError):
+            pass
         roofline = {'bound': 'hbm', 'kernel': cand[dom][1], 'entry_point': dom,
                     'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+                    'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
                     'algorithmic_bytes_per_launch': bytes_per_launch,
                     'avg_launch_ms': round(hip_ms[dom], 4)}
         ms_per_step = elapsed / args.steps * 1e3
