@@ -1,0 +1,408 @@
+// Fused forward of the per-edge graph of a PCFLayer (self neighbourhoods) on gfx950.
+//
+//        VI[e] (<=12) --mlp_conv--> pe (<=32) --+                           guidance branch
+//                                               +-- Wb.pe + u[idx[e]] - (same for the key edge) + b
+//                                                   --BN,ReLU--> h1 (8) --g2,BN,sigmoid--> score (H <= 8)
+//        VI[e] --w1--> a1 (8) --w2--> a2 (8) --w3--> w (Cm <= 16)         WeightNet branch (BN+ReLU each)
+//
+// (layers.py:361-384 with MultiHeadGuidance :47-68 and WeightNet :163-171; u = Wa.guidance_x is the
+// per-point half of the first guidance layer, see pcf_hip_rowlin_*_ex.)  In training every BatchNorm
+// needs the statistics of its pre-activation over ALL edges before the next layer can run, which is
+// three dependent global reductions.  Layer-at-a-time execution (edge_mlp.hip) costs 12 kernels that
+// stream [E, 8..32] activations back and forth; here the chain is RECOMPUTED from the 48-byte VI row in
+// each of four passes, a pass ending at the first layer whose statistics are still unknown:
+//     pass 1: statistics of mlp_conv and w1                      (reads VI)
+//     pass 2: writes pe, a1;  statistics of g1 and w2            (reads VI, idx, u)
+//     pass 3: writes h1, a2;  statistics of g2 and w3
+//     pass 4: writes score, w                                    (the aggregate kernel consumes them)
+// The activations are written once because the backward kernels need them; in inference (running
+// statistics) only pass 4 runs and nothing but score and w is written.  One lane owns one edge; all six
+// weight matrices sit in LDS (5 KB) and are read as wave-wide broadcasts; per-channel sums go through
+// the same 64x16 LDS transposition as edge_mlp.hip.  HBM-bound: 4 x 48 B + 3 x 40 B read, 392 B written
+// per edge at the BASELINE shape against ~2 kB for the layer-at-a-time path.
+#include <algorithm>
+
+#include "pcf_common.h"
+
+namespace pcf {
+
+constexpr int CV = 12;     // max width of the WeightNet input (VI: 12, plain offsets: 3)
+constexpr int CG = 32;     // max width of the positional encoding (guidance_feat_len)
+constexpr int CH = 8;      // hidden width of the guidance MLP and of WeightNet
+constexpr int CHD = 8;     // max heads
+constexpr int CMX = 16;    // max C_mid
+
+enum { L_PE = 0, L_G1 = 1, L_G2 = 2, L_W1 = 3, L_W2 = 4, L_W3 = 5 };
+
+struct ChainArgs {
+    const float* vi;            // [E, cv]
+    const int64_t* idx;         // [E] batch-local neighbour index of every edge (for u)
+    const float* u;             // [B*N, 8]
+    long long E, rows_per_batch;
+    int N, K, cv, g, heads, cm;
+    const float* W[6];
+    const float* b[6];
+    const float* gamma[6];
+    const float* beta[6];
+    const float* mean[6];       // device [64] each; filled pass by pass
+    const float* rstd[6];
+    float* pe; float* a1; float* h1; float* a2; float* score; float* w;
+    float* part;                // [blocks][2][64] partial sums of the pass
+    int vec_vi;
+};
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- the chain on the matrix cores --------------------------------------------------------------------
+// Transposed formulation: for a tile of 16 edges, Z[o][p] = sum_c W[o][c] * Y[c][p] with
+// v_mfma_f32_16x16x4_f32 (exact fp32).  Accumulator layout (C/D map): lane l, register r holds
+// channel 4*(l>>4) + r of edge p = l & 15.  The B operand wants, for contraction step k = l>>4, one value
+// per lane of edge l & 15 -- so register s of the previous layer's accumulator IS the B operand of
+// contraction step s if that step is defined to cover channels {4k + s}: the contraction order is a free
+// choice as long as the weight fragment follows it (A[o][k] = W[o][4k + s]).  Hence
+//   * the six weight matrices live in 32 VGPRs for the whole kernel (loaded once),
+//   * a layer's output feeds the next layer with NO data movement (no LDS, no shuffles),
+//   * BatchNorm parameters are per-lane constants (channel 4*(l>>4)+r), statistics are per-lane running
+//     sums over tiles, reduced across the 16 edge lanes once at the end.
+// K <= 16 so a neighbourhood never straddles a tile (the key edge is lane l & ~(K-1) of the same group).
+__device__ __forceinline__ float wfrag(const float* W, int Cout, int Cin, int o, int c) {
+    return (W && o < Cout && c < Cin) ? W[o * Cin + c] : 0.f;
+}
+
+// BatchNorm constants of output-tile slot `f` (0 pe lo, 1 pe hi, 2 w1, 3 g1, 4 w2, 5 g2, 6 w3), channel c of the
+// tile: BN(acc + bias) = acc * scale + shift.  Kept in LDS ([slot][scale|shift][16]); a lane reads its four
+// channels 4g..4g+3 with one ds_read_b128 each when a tile needs them, instead of pinning 56 VGPRs.
+__device__ __forceinline__ void stage_frags(const ChainArgs& a, float (*cf)[2][16], int level) {
+    const int layer_of[7] = {L_PE, L_PE, L_W1, L_G1, L_W2, L_G2, L_W3};
+    const int tile_of[7] = {0, 1, 0, 0, 0, 0, 0};
+    const int cout_of[7] = {a.g, a.g, CH, CH, CH, a.heads, a.cm};
+    const int need_level[7] = {2, 2, 2, 3, 3, 4, 4};        // statistics of slot f exist from this level on
+    for (int t = threadIdx.x; t < 7 * 16; t += BLOCK) {
+        const int f = t >> 4, c = t & 15;
+        const int layer = layer_of[f], o = 16 * tile_of[f] + c;
+        float sc = 1.f, sh = 0.f;
+        if (o < cout_of[f] && level >= need_level[f]) {
+            sc = a.rstd[layer][o] * a.gamma[layer][o];
+            sh = (a.b[layer][o] - a.mean[layer][o]) * sc + a.beta[layer][o];
+        }
+        cf[f][0][c] = sc;
+        cf[f][1][c] = sh;
+    }
+}
+
+__device__ __forceinline__ f32x4 bn_relu(f32x4 v, const float (*cf)[16], int g) {
+    const float4 sc = ld4(&cf[0][4 * g]), sh = ld4(&cf[1][4 * g]);
+    v[0] = fmaxf(v[0] * sc.x + sh.x, 0.f); v[1] = fmaxf(v[1] * sc.y + sh.y, 0.f);
+    v[2] = fmaxf(v[2] * sc.z + sh.z, 0.f); v[3] = fmaxf(v[3] * sc.w + sh.w, 0.f);
+    return v;
+}
+__device__ __forceinline__ f32x4 bn_only(f32x4 v, const float (*cf)[16], int g) {
+    const float4 sc = ld4(&cf[0][4 * g]), sh = ld4(&cf[1][4 * g]);
+    v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y; v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
+    return v;
+}
+
+#define PCF_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_16x16x4f32((A), (B), (C), 0, 0, 0)
+
+template <int LEVEL>
+__global__ __launch_bounds__(BLOCK) void pcf_chain_kernel(const ChainArgs a) {
+    __shared__ float red[NWAVE][3][2][16];
+    __shared__ __align__(16) float cf[7][2][16];
+    stage_frags(a, cf, LEVEL);
+    __syncthreads();
+    const int lane = lane_id(), wave = wave_id();
+    const int p = lane & 15, g = lane >> 4;
+    // weight fragments: wf[s] = W[o = 16*tile + p][c = 16*utile + 4*g + s]
+    f32x4 w_pe[2], w_w1, w_g1[2], w_w2, w_g2, w_w3;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        w_pe[0][s] = wfrag(a.W[L_PE], a.g, a.cv, p, 4 * g + s);
+        w_pe[1][s] = wfrag(a.W[L_PE], a.g, a.cv, 16 + p, 4 * g + s);
+        w_w1[s] = wfrag(a.W[L_W1], CH, a.cv, p, 4 * g + s);
+        w_g1[0][s] = LEVEL >= 2 ? wfrag(a.W[L_G1], CH, a.g, p, 4 * g + s) : 0.f;
+        w_g1[1][s] = LEVEL >= 2 ? wfrag(a.W[L_G1], CH, a.g, p, 16 + 4 * g + s) : 0.f;
+        w_w2[s] = LEVEL >= 2 ? wfrag(a.W[L_W2], CH, CH, p, 4 * g + s) : 0.f;
+        w_g2[s] = LEVEL >= 3 ? wfrag(a.W[L_G2], a.heads, CH, p, 4 * g + s) : 0.f;
+        w_w3[s] = LEVEL >= 3 ? wfrag(a.W[L_W3], a.cm, CH, p, 4 * g + s) : 0.f;
+    }
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 s1[3] = {zero4, zero4, zero4}, s2[3] = {zero4, zero4, zero4};     // statistics of raw accumulators (bias added later)
+    const int lead = (lane & ~15) | (p & ~(a.K - 1));
+    const long long ntiles = a.E / 16;
+    const long long tstride = (long long)gridDim.x * NWAVE;
+    // Loads of tile t+1 (VI, neighbour index) and the gathered u row of tile t+1 are issued before the
+    // MFMAs of tile t: one wave keeps two tiles of global loads in flight behind ~1000 cycles of matrix work.
+    auto load_x = [&](long long tt) -> f32x4 {
+        f32x4 xv = zero4;
+        if (tt < ntiles && 4 * g < a.cv) {
+            const float* q = a.vi + (size_t)(tt * 16 + p) * a.cv + 4 * g;
+            if (a.vec_vi) { const float4 v = ld4(q); xv[0] = v.x; xv[1] = v.y; xv[2] = v.z; xv[3] = v.w; }
+            else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xv[r] = (4 * g + r < a.cv) ? q[r] : 0.f;
+            }
+        }
+        return xv;
+    };
+    auto load_j = [&](long long tt) -> long long {
+        if (LEVEL < 2 || g >= 2 || tt >= ntiles) return -1;
+        const int64_t j = a.idx[tt * 16 + p];
+        return (j >= 0 && j < a.N) ? (long long)((tt * 16 + p) / a.rows_per_batch) * a.N + j : -1;
+    };
+    auto load_u = [&](long long row) -> f32x4 {
+        f32x4 uv = zero4;
+        if (LEVEL >= 2 && row >= 0) { const float4 v = ld4(a.u + (size_t)row * CH + 4 * g); uv[0] = v.x; uv[1] = v.y; uv[2] = v.z; uv[3] = v.w; }
+        return uv;
+    };
+    long long t = (long long)blockIdx.x * NWAVE + wave;
+    f32x4 x = load_x(t), x_next = load_x(t + tstride);
+    f32x4 ucur = load_u(load_j(t));
+    long long j_next = load_j(t + tstride);
+    for (; t < ntiles; t += tstride) {
+        const long long e = t * 16 + p;
+        asm volatile("" ::: "memory");     // keeps the (loop-invariant) BN constants in LDS instead of 56 pinned VGPRs
+        const f32x4 u_next = load_u(j_next);                       // gather for tile t+1
+        const long long j_nn = load_j(t + 2 * tstride);            // index for tile t+2
+        const f32x4 x_nn = load_x(t + 2 * tstride);                // input of tile t+2
+        f32x4 pe0 = zero4, pe1 = zero4, a1 = zero4;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            pe0 = PCF_MFMA(w_pe[0][s], x[s], pe0);
+            pe1 = PCF_MFMA(w_pe[1][s], x[s], pe1);
+            a1 = PCF_MFMA(w_w1[s], x[s], a1);
+        }
+        if (LEVEL == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s1[0][r] += pe0[r]; s2[0][r] += pe0[r] * pe0[r];
+                s1[1][r] += pe1[r]; s2[1][r] += pe1[r] * pe1[r];
+                s1[2][r] += a1[r];  s2[2][r] += a1[r] * a1[r];
+            }
+            x = x_next; x_next = x_nn; ucur = u_next; j_next = j_nn;
+            continue;
+        }
+        pe0 = bn_relu(pe0, cf[0], g);
+        pe1 = bn_relu(pe1, cf[1], g);
+        a1 = bn_relu(a1, cf[2], g);
+        if (LEVEL == 2) {
+            if (a.pe) {
+                float* q = a.pe + (size_t)e * a.g;
+                if ((a.g & 3) == 0) {
+                    if (4 * g < a.g) st4(q + 4 * g, make_float4(pe0[0], pe0[1], pe0[2], pe0[3]));
+                    if (16 + 4 * g < a.g) st4(q + 16 + 4 * g, make_float4(pe1[0], pe1[1], pe1[2], pe1[3]));
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (4 * g + r < a.g) q[4 * g + r] = pe0[r];
+                        if (16 + 4 * g + r < a.g) q[16 + 4 * g + r] = pe1[r];
+                    }
+                }
+            }
+            if (a.a1 && g < 2) st4(a.a1 + (size_t)e * CH + 4 * g, make_float4(a1[0], a1[1], a1[2], a1[3]));
+        }
+        // g1: Wb.pe + u[idx[e]] - (same for the key edge);  w2
+        f32x4 h1 = zero4, h1b = zero4, a2 = zero4;      // two accumulators halve the dependent-MFMA chain of g1
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            h1 = PCF_MFMA(w_g1[0][s], pe0[s], h1);
+            h1b = PCF_MFMA(w_g1[1][s], pe1[s], h1b);
+            a2 = PCF_MFMA(w_w2[s], a1[s], a2);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h1[r] += h1b[r];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h1[r] += ucur[r];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h1[r] -= __shfl(h1[r], lead, WAVE);
+        if (LEVEL == 2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s1[0][r] += h1[r]; s2[0][r] += h1[r] * h1[r];
+                s1[1][r] += a2[r]; s2[1][r] += a2[r] * a2[r];
+            }
+            x = x_next; x_next = x_nn; ucur = u_next; j_next = j_nn;
+            continue;
+        }
+        h1 = bn_relu(h1, cf[3], g);
+        a2 = bn_relu(a2, cf[4], g);
+        if (LEVEL == 3 && g < 2) {
+            if (a.h1) st4(a.h1 + (size_t)e * CH + 4 * g, make_float4(h1[0], h1[1], h1[2], h1[3]));
+            if (a.a2) st4(a.a2 + (size_t)e * CH + 4 * g, make_float4(a2[0], a2[1], a2[2], a2[3]));
+        }
+        f32x4 sc = zero4, wv = zero4;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            sc = PCF_MFMA(w_g2[s], h1[s], sc);
+            wv = PCF_MFMA(w_w3[s], a2[s], wv);
+        }
+        if (LEVEL == 3) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s1[0][r] += sc[r]; s2[0][r] += sc[r] * sc[r];
+                s1[1][r] += wv[r]; s2[1][r] += wv[r] * wv[r];
+            }
+            x = x_next; x_next = x_nn; ucur = u_next; j_next = j_nn;
+            continue;
+        }
+        sc = bn_only(sc, cf[5], g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sc[r] = 1.f / (1.f + __expf(-sc[r]));
+        wv = bn_relu(wv, cf[6], g);
+        {
+            float* qs = a.score + (size_t)e * a.heads;
+            float* qw = a.w + (size_t)e * a.cm;
+            if ((a.heads & 3) == 0) { if (4 * g < a.heads) st4(qs + 4 * g, make_float4(sc[0], sc[1], sc[2], sc[3])); }
+            else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (4 * g + r < a.heads) qs[4 * g + r] = sc[r];
+            }
+            if ((a.cm & 3) == 0) { if (4 * g < a.cm) st4(qw + 4 * g, make_float4(wv[0], wv[1], wv[2], wv[3])); }
+            else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (4 * g + r < a.cm) qw[4 * g + r] = wv[r];
+            }
+        }
+        x = x_next; x_next = x_nn; ucur = u_next; j_next = j_nn;
+    }
+    if (LEVEL == 4) return;
+    // reduce the per-lane sums over the 16 edge lanes; lane p == 0 of group g then owns channels 4g..4g+3
+#pragma unroll
+    for (int gi = 0; gi < 3; ++gi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v1 = s1[gi][r], v2 = s2[gi][r];
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) { v1 += __shfl_xor(v1, off, WAVE); v2 += __shfl_xor(v2, off, WAVE); }
+            if (p == 0) { red[wave][gi][0][4 * g + r] = v1; red[wave][gi][1][4 * g + r] = v2; }
+        }
+    __syncthreads();
+    if (threadIdx.x < 96) {
+        const int gi = threadIdx.x / 32, which = (threadIdx.x >> 4) & 1, c = threadIdx.x & 15;
+        float tsum = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWAVE; ++w) tsum += red[w][gi][which][c];
+        a.part[(size_t)blockIdx.x * 96 + threadIdx.x] = tsum;
+    }
+}
+
+// Statistics of one pass: up to three groups of 16 channels; each group belongs to a layer at a channel
+// offset.  One thread per (group, channel): fp64 sum over the workgroup partials.
+struct FinGroup { float* mean; float* rstd; float* running_mean; float* running_var; const float* bias; int chan0; int count; };
+struct FinArgs { FinGroup g[3]; const float* part; int nblocks; long long R; float eps; float momentum; };
+
+__global__ __launch_bounds__(1024) void chain_finalize_kernel(const FinArgs f) {
+    // 96 values (3 groups x {sum, sum of squares} x 16 channels) x 10 slices of the partial list
+    __shared__ double sh[10][96];
+    const int v = threadIdx.x % 96, slice = threadIdx.x / 96;
+    if (slice < 10) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int p = slice;
+        for (; p + 30 < f.nblocks; p += 40) {
+            a0 += (double)f.part[(size_t)p * 96 + v];
+            a1 += (double)f.part[(size_t)(p + 10) * 96 + v];
+            a2 += (double)f.part[(size_t)(p + 20) * 96 + v];
+            a3 += (double)f.part[(size_t)(p + 30) * 96 + v];
+        }
+        for (; p < f.nblocks; p += 10) a0 += (double)f.part[(size_t)p * 96 + v];
+        sh[slice][v] = (a0 + a1) + (a2 + a3);
+    }
+    __syncthreads();
+    if (threadIdx.x < 48) {
+        const int gi = threadIdx.x >> 4, c = threadIdx.x & 15;
+        double sums[2] = {0.0, 0.0};
+#pragma unroll
+        for (int which = 0; which < 2; ++which)
+#pragma unroll
+            for (int sl = 0; sl < 10; ++sl) sums[which] += sh[sl][gi * 32 + which * 16 + c];
+        const FinGroup& g = f.g[gi];
+        if (g.mean && c < g.count) {
+            const int o = g.chan0 + c;
+            const double n = (double)f.R;
+            const double m0 = sums[0] / n;                  // statistics of z - bias
+            double var = sums[1] / n - m0 * m0;
+            if (var < 0.0) var = 0.0;
+            const double mean = m0 + (double)g.bias[o];
+            g.mean[o] = (float)mean;
+            g.rstd[o] = (float)(1.0 / sqrt(var + (double)f.eps));
+            if (g.running_mean) {
+                const double unb = f.R > 1 ? var * n / (n - 1.0) : var;
+                g.running_mean[o] = (float)((1.0 - f.momentum) * g.running_mean[o] + f.momentum * mean);
+                g.running_var[o] = (float)((1.0 - f.momentum) * g.running_var[o] + f.momentum * unb);
+            }
+        }
+    }
+}
+
+template <typename KernelT>
+static int chain_grid(KernelT, long long E) {
+    const long long tiles = E / 16;
+    return (int)std::max<long long>(1, std::min<long long>((tiles + NWAVE - 1) / NWAVE, 1024));    // 4 workgroups x 256 CUs
+}
+
+}  // namespace pcf
+
+extern "C" {
+
+size_t pcf_hip_pcf_chain_workspace_bytes(void) { return (size_t)1024 * 96 * 4 + 1024; }
+
+// stats [12][64] floats (device): mean of layer l at stats + l*64, rstd at stats + (6 + l)*64, l in the
+// order mlp_conv, g1, g2, w1, w2, w3.  Training (batch_stats != 0): computed here and the running
+// statistics (nullable) updated; inference: the caller fills them from the running statistics.
+int pcf_hip_pcf_chain_forward(const float* vi, const int64_t* idx, const float* u, long long E, long long rows_per_batch,
+                              int N, int K, int cv, int g, int heads, int cm, const float* const* W, const float* const* b,
+                              const float* const* gamma, const float* const* beta, float* const* running_mean,
+                              float* const* running_var, float eps, float momentum, int batch_stats, float* stats,
+                              float* pe, float* a1, float* h1, float* a2, float* score, float* w, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+    using namespace pcf;
+    PCF_REQUIRE(E >= 0 && rows_per_batch > 0 && N >= 0, "pcf_chain: bad sizes");
+    if (cv < 1 || cv > CV || g < 1 || g > CG || heads < 1 || heads > CHD || cm < 1 || cm > CMX)
+        return fail(PCF_E_UNSUPPORTED, "pcf_chain: widths outside the fused kernel (cv=%d<=12, g=%d<=32, heads=%d<=8, cm=%d<=16)", cv, g, heads, cm);
+    if (K < 1 || K > 16 || (K & (K - 1)) != 0 || E % 16 != 0 || E % rows_per_batch != 0)
+        return fail(PCF_E_UNSUPPORTED, "pcf_chain: K must be a power of two <= 16 and the edge count a multiple of 16 (K=%d)", K);
+    if (E == 0) return ok();
+    PCF_REQUIRE(vi && idx && u && W && b && gamma && beta && stats && score && w, "pcf_chain: null pointer");
+    PCF_REQUIRE(!batch_stats || (pe && a1 && h1 && a2), "pcf_chain: training needs the activation buffers");
+    PCF_REQUIRE(aligned16(score) && aligned16(w) && aligned16(pe) && aligned16(a1) && aligned16(h1) && aligned16(a2) &&
+                    aligned16(u), "pcf_chain: buffers must be 16-byte aligned");
+    PCF_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= pcf_hip_pcf_chain_workspace_bytes(),
+                "pcf_chain: workspace too small or misaligned");
+    hipStream_t s = (hipStream_t)stream;
+    ChainArgs a{};
+    a.vi = vi; a.idx = idx; a.u = u; a.E = E; a.rows_per_batch = rows_per_batch; a.N = N; a.K = K;
+    a.cv = cv; a.g = g; a.heads = heads; a.cm = cm;
+    for (int l = 0; l < 6; ++l) {
+        PCF_REQUIRE(W[l] && b[l] && gamma[l] && beta[l], "pcf_chain: null parameter of layer %d", l);
+        a.W[l] = W[l]; a.b[l] = b[l]; a.gamma[l] = gamma[l]; a.beta[l] = beta[l];
+        a.mean[l] = stats + l * 64; a.rstd[l] = stats + (6 + l) * 64;
+    }
+    a.pe = pe; a.a1 = a1; a.h1 = h1; a.a2 = a2; a.score = score; a.w = w;
+    a.part = static_cast<float*>(workspace);
+    a.vec_vi = (cv % 4 == 0) && aligned16(vi);
+    if (batch_stats) {
+        for (int pass = 0; pass < 3; ++pass) {
+            int grid;
+            if (pass == 0) { grid = chain_grid(pcf_chain_kernel<1>, E); hipLaunchKernelGGL(pcf_chain_kernel<1>, dim3(grid), dim3(BLOCK), 0, s, a); }
+            else if (pass == 1) { grid = chain_grid(pcf_chain_kernel<2>, E); hipLaunchKernelGGL(pcf_chain_kernel<2>, dim3(grid), dim3(BLOCK), 0, s, a); }
+            else { grid = chain_grid(pcf_chain_kernel<3>, E); hipLaunchKernelGGL(pcf_chain_kernel<3>, dim3(grid), dim3(BLOCK), 0, s, a); }
+            if (int e = check_launch("pcf_chain pass")) return e;
+            FinArgs f{};
+            f.part = a.part; f.nblocks = grid; f.R = E; f.eps = eps; f.momentum = momentum;
+            auto set = [&](int gi, int layer, int chan0, int count) {
+                f.g[gi].mean = stats + layer * 64; f.g[gi].rstd = stats + (6 + layer) * 64;
+                f.g[gi].running_mean = running_mean ? running_mean[layer] : nullptr;
+                f.g[gi].running_var = running_var ? running_var[layer] : nullptr;
+                f.g[gi].bias = b[layer]; f.g[gi].chan0 = chan0; f.g[gi].count = count;
+            };
+            if (pass == 0) { set(0, L_PE, 0, std::min(g, 16)); set(1, L_PE, 16, std::max(g - 16, 0)); set(2, L_W1, 0, CH); }
+            else if (pass == 1) { set(0, L_G1, 0, CH); set(1, L_W2, 0, CH); }
+            else { set(0, L_G2, 0, heads); set(1, L_W3, 0, cm); }
+            hipLaunchKernelGGL(chain_finalize_kernel, dim3(1), dim3(1024), 0, s, f);
+            if (int e = check_launch("pcf_chain finalize")) return e;
+        }
+    }
+    hipLaunchKernelGGL(pcf_chain_kernel<4>, dim3(chain_grid(pcf_chain_kernel<4>, E)), dim3(BLOCK), 0, s, a);
+    return check_launch("pcf_chain final pass");
+}
+
+}  // extern "C"

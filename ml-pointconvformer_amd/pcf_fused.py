@@ -376,3 +376,133 @@ def wide_linear_bn_act(x, weight, bias, bn, act, training):
     momentum = 0.1 if bn.momentum is None else bn.momentum
     return _WideLinearBNAct.apply(x, weight, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, momentum,
                                   use_batch, act)
+
+
+# --------------------------------------------------------------------------------------------------
+# fused forward of the PCFLayer edge graph (csrc/edge_chain.hip) + aggregate; backward layer by layer
+# --------------------------------------------------------------------------------------------------
+_PP = ctypes.POINTER(ctypes.c_void_p)
+_chain_ws = getattr(_lib, 'pcf_hip_pcf_chain_workspace_bytes')
+_chain_ws.argtypes = []
+_chain_ws.restype = _Z
+_chain_fwd = _sig('pcf_hip_pcf_chain_forward',
+                  [_P, _P, _P, _LL, _LL, _I, _I, _I, _I, _I, _I, _PP, _PP, _PP, _PP, _PP, _PP, _F, _F, _I, _P,
+                   _P, _P, _P, _P, _P, _P, _P, _Z, _P])
+
+
+def _ptr_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = None if t is None else t.data_ptr()
+    return arr
+
+
+def _rowlin_backward_raw(x, dy, W, b, mean, rstd, gamma, beta, training, act, need_dx, gadd=None, gidx=None, group=0):
+    """One layer of the chain backwards through csrc/edge_mlp.hip -> (dx, dW, db, dgamma, dbeta, dgadd)."""
+    Cout, Cin = W.shape
+    R = x.numel() // Cin
+    dev = x.device
+    dx = torch.empty_like(x) if need_dx else None
+    dW, db = torch.empty_like(W), torch.empty_like(b)
+    dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
+    dgadd = torch.empty_like(gadd) if gadd is not None else None
+    rpb = gidx[0].numel() if gadd is not None else 0
+    gN = gadd.shape[-2] if gadd is not None else 0
+    nbytes = _rowlin_ws(Cin, Cout)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    _call(_rowlin_bwd, _ptr(x), _ptr(dy), R, Cin, _ptr(W), _ptr(b), Cout, mean.data_ptr(), rstd.data_ptr(), _ptr(gamma),
+          _ptr(beta), 1 if training else 0, act, _ptr(gadd), _ptr(gidx) if gadd is not None else None, rpb, gN, group,
+          _ptr(dx), _ptr(dW), _ptr(db), _ptr(dgamma), _ptr(dbeta), _ptr(dgadd), ws.data_ptr(), nbytes, _stream(dev))
+    return dx, dW, db, dgamma, dbeta, dgadd
+
+
+class _PCFChain(torch.autograd.Function):
+    """agg = aggregate(fx, idx, score, w) with score / w produced by the fused edge chain.
+
+    Tensor inputs: vi [B,M,K,cv], u [B,N,8], fx [B,N,Ci], then (W, b, gamma, beta) of the six layers in the
+    order mlp_conv, g1 (positional half of the weight), g2, w1, w2, w3.  `bns` are the six BatchNorm1d modules
+    (running statistics are updated in place in training)."""
+
+    @staticmethod
+    def forward(ctx, idx, bns, training, vi, u, fx, *params):
+        dev = vi.device
+        B, M, K, cv = vi.shape
+        N = u.shape[1]
+        Ws, bs, gammas, betas = params[0::4], params[1::4], params[2::4], params[3::4]
+        g, heads, cm = Ws[0].shape[0], Ws[2].shape[0], Ws[5].shape[0]
+        E = B * M * K
+        stats = torch.empty(12, 64, dtype=torch.float32, device=dev)
+        if not training:
+            for l, bn in enumerate(bns):
+                c = bn.running_mean.numel()
+                stats[l, :c] = bn.running_mean
+                stats[6 + l, :c] = torch.rsqrt(bn.running_var + bn.eps)
+        f32 = dict(dtype=torch.float32, device=dev)
+        score = torch.empty(B, M, K, heads, **f32)
+        w = torch.empty(B, M, K, cm, **f32)
+        pe = a1 = h1 = a2 = None
+        if training:
+            pe, a1 = torch.empty(B, M, K, g, **f32), torch.empty(B, M, K, 8, **f32)
+            h1, a2 = torch.empty(B, M, K, 8, **f32), torch.empty(B, M, K, 8, **f32)
+            for bn in bns:
+                if bn.num_batches_tracked is not None:
+                    bn.num_batches_tracked += 1
+        nbytes = _chain_ws()
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        keep = [t.contiguous() for t in params]
+        Ws, bs, gammas, betas = keep[0::4], keep[1::4], keep[2::4], keep[3::4]
+        rm = _ptr_array([bn.running_mean for bn in bns]) if training else None
+        rv = _ptr_array([bn.running_var for bn in bns]) if training else None
+        mom = bns[0].momentum if bns[0].momentum is not None else 0.1
+        with torch.cuda.device(dev):
+            _call(_chain_fwd, _ptr(vi), _ptr(idx), _ptr(u), E, M * K, N, K, cv, g, heads, cm, _ptr_array(Ws), _ptr_array(bs),
+                  _ptr_array(gammas), _ptr_array(betas), rm, rv, float(bns[0].eps), float(mom), 1 if training else 0,
+                  stats.data_ptr(), _ptr(pe), _ptr(a1), _ptr(h1), _ptr(a2), _ptr(score), _ptr(w), ws.data_ptr(), nbytes,
+                  _stream(dev))
+        agg = pcf_cuda.pcf_forward(fx, idx, score, w)
+        ctx.save_for_backward(idx, vi, u, fx, stats, pe, a1, h1, a2, score, w, *keep)
+        ctx.training = bool(training)
+        return agg
+
+    @staticmethod
+    def backward(ctx, dagg):
+        idx, vi, u, fx, stats, pe, a1, h1, a2, score, w, *keep = ctx.saved_tensors
+        if pe is None:
+            raise RuntimeError('pcf_chain: backward needs the training-mode forward (activations were not kept)')
+        Ws, bs, gammas, betas = keep[0::4], keep[1::4], keep[2::4], keep[3::4]
+        tr = ctx.training
+        K = idx.shape[2]
+        st = lambda l: (stats[l], stats[6 + l])
+        with torch.cuda.device(dagg.device):
+            dfx, dscore, dw = pcf_cuda.pcf_backward(dagg.contiguous(), fx, idx, score, w)
+            L = {}
+            dh1, *L[2] = _rowlin_backward_raw(h1, dscore, Ws[2], bs[2], *st(2), gammas[2], betas[2], tr, ACT_SIGMOID, True)[:5]
+            r = _rowlin_backward_raw(pe, dh1, Ws[1], bs[1], *st(1), gammas[1], betas[1], tr, ACT_RELU, True, gadd=u, gidx=idx, group=K)
+            dpe, L[1], du = r[0], list(r[1:5]), r[5]
+            L[0] = list(_rowlin_backward_raw(vi, dpe, Ws[0], bs[0], *st(0), gammas[0], betas[0], tr, ACT_RELU, False)[1:5])
+            da2, *L[5] = _rowlin_backward_raw(a2, dw, Ws[5], bs[5], *st(5), gammas[5], betas[5], tr, ACT_RELU, True)[:5]
+            da1, *L[4] = _rowlin_backward_raw(a1, da2, Ws[4], bs[4], *st(4), gammas[4], betas[4], tr, ACT_RELU, True)[:5]
+            L[3] = list(_rowlin_backward_raw(vi, da1, Ws[3], bs[3], *st(3), gammas[3], betas[3], tr, ACT_RELU, False)[1:5])
+        grads = []
+        for l in range(6):
+            grads.extend(L[l])
+        return (None, None, None, None, du, dfx, *grads)
+
+
+def pcf_chain_supported(cv, g, heads, cm, K, hidden_ok, n_edges):
+    """Shapes the fused MFMA chain covers: a neighbourhood must fit one 16-edge tile."""
+    return hidden_ok and 1 <= cv <= 12 and 1 <= g <= 32 and 1 <= heads <= 8 and 1 <= cm <= 16 \
+        and 1 <= K <= 16 and (K & (K - 1)) == 0 and n_edges % 16 == 0
+
+
+def pcf_chain(vi, idx, u, fx, layers, training):
+    """layers: six (nn.Linear, nn.BatchNorm1d) pairs in the order mlp_conv, g1, g2, w1, w2, w3; the g1 weight is
+    split here (its gathered half already went into `u`)."""
+    _floats(vi=vi, u=u, fx=fx)
+    _check_input(idx, 'nei_inds', torch.int64)
+    G = layers[0][0].out_features
+    params = []
+    for l, (lin, bn) in enumerate(layers):
+        W = lin.weight[:, lin.weight.shape[1] - G:] if l == 1 else lin.weight
+        params += [W, lin.bias, bn.weight, bn.bias]
+    return _PCFChain.apply(idx, [bn for _, bn in layers], training, vi, u, fx, *params)

@@ -313,6 +313,22 @@ class PCFLayer(nn.Module):
         self.unary_shortcut = UnaryBlock(in_channel, out_channel, use_bn=True, bn_momentum=0.1, no_relu=True) \
             if in_channel != out_channel else nn.Identity()
 
+    def _chain_layers(self, wn_in, nei_inds):
+        """The six (Linear, BatchNorm) pairs of the edge graph if the fused chain kernel covers this layer
+        (csrc/edge_chain.hip), else None."""
+        if getattr(self.cfg, 'NO_EDGE_CHAIN', False) or getattr(self.cfg, 'DETERMINISTIC_BACKWARD', False):
+            return None
+        gw, wn = self.guidance_weight.mlp, self.weightnet.mlp_convs
+        mods = [self.mlp_conv] + list(gw) + list(wn)
+        if len(gw) != 2 or len(wn) != 3 or not all(isinstance(m, Linear_BN) for m in mods):
+            return None
+        hidden_ok = gw[0].c.out_features == 8 and wn[0].c.out_features == 8 and wn[1].c.out_features == 8 \
+            and gw[0].c.in_features == 2 * self.mlp_conv.c.out_features
+        if not pcf_fused.pcf_chain_supported(wn_in.shape[-1], self.mlp_conv.c.out_features, gw[1].c.out_features,
+                                             wn[2].c.out_features, nei_inds.shape[2], hidden_ok, nei_inds.numel()):
+            return None
+        return [(m.c, m.bn) for m in mods]
+
     def forward(self, dense_xyz, dense_feats, nei_inds, dense_xyz_norm, sparse_xyz=None, sparse_xyz_norm=None,
                 vi_features=None, inv_neighbors=None, inv_k=None, inv_idx=None):
         strided = sparse_xyz is not None
@@ -322,21 +338,30 @@ class PCFLayer(nn.Module):
         feats_x = self.unary1(dense_feats)
         _, wn_in = _edge_geometry(self.cfg.USE_VI is True, dense_xyz, dense_xyz_norm, nei_inds, ctr_xyz, ctr_norm,
                                   vi_features)
-        feat_pe = _linear_act(self.mlp_conv, wn_in, pcf_fused.ACT_RELU)
         guidance_x = self.guidance_unary(feats_x)
-        if not strided and pcf_fused.split_guidance_supported(nei_inds.shape[2], 8) \
-                and pcf_fused.rowlin_supported(feat_pe.shape[-1], 8):
-            # self neighbourhoods: key = neighbour 0; the first guidance layer absorbs the q - key algebra
-            guidance_score = self.guidance_weight.forward_split(guidance_x.contiguous(), nei_inds, feat_pe)
+        chain = self._chain_layers(wn_in, nei_inds) if not strided else None
+        if chain is not None:
+            # self neighbourhoods, BatchNorm everywhere: the whole edge graph in four fused passes
+            g1 = self.guidance_weight.mlp[0].c
+            G = guidance_x.shape[-1]
+            u = pcf_fused.linear_bn_act(guidance_x, g1.weight[:, :G], g1.weight.new_zeros(g1.out_features), None,
+                                        pcf_fused.ACT_NONE, self.training)
+            agg = pcf_fused.pcf_chain(wn_in.contiguous(), nei_inds, u, feats_x.contiguous(), chain, self.training)
         else:
-            # strided: key = max over the neighbourhood, formed explicitly in one kernel
-            diff = pcf_fused.guidance_diff(guidance_x.contiguous(), nei_inds, feat_pe, use_max=strided)
-            guidance_score = self.guidance_weight.forward_diff(diff)
-        weights = self.weightnet(wn_in)
-        if not getattr(self.cfg, 'DETERMINISTIC_BACKWARD', False):
-            inv_neighbors = inv_k = inv_idx = None      # float atomics are ~25 % faster than the CSR reduce here
-        agg = PCF.forward(feats_x.contiguous(), nei_inds, guidance_score.contiguous(), weights.contiguous(),
-                          inv_neighbors, inv_k, inv_idx)
+            feat_pe = _linear_act(self.mlp_conv, wn_in, pcf_fused.ACT_RELU)
+            if not strided and pcf_fused.split_guidance_supported(nei_inds.shape[2], 8) \
+                    and pcf_fused.rowlin_supported(feat_pe.shape[-1], 8):
+                # self neighbourhoods: key = neighbour 0; the first guidance layer absorbs the q - key algebra
+                guidance_score = self.guidance_weight.forward_split(guidance_x.contiguous(), nei_inds, feat_pe)
+            else:
+                # strided: key = max over the neighbourhood, formed explicitly in one kernel
+                diff = pcf_fused.guidance_diff(guidance_x.contiguous(), nei_inds, feat_pe, use_max=strided)
+                guidance_score = self.guidance_weight.forward_diff(diff)
+            weights = self.weightnet(wn_in)
+            if not getattr(self.cfg, 'DETERMINISTIC_BACKWARD', False):
+                inv_neighbors = inv_k = inv_idx = None      # float atomics are ~25 % faster than the CSR reduce here
+            agg = PCF.forward(feats_x.contiguous(), nei_inds, guidance_score.contiguous(), weights.contiguous(),
+                              inv_neighbors, inv_k, inv_idx)
         new_feat = self.unary2(self.dropout(_linear_act(self.linear, agg, pcf_fused.ACT_RELU)))
         sparse_feats = pcf_fused.gather_max(dense_feats, nei_inds) if strided else dense_feats
         shortcut = self.unary_shortcut(sparse_feats)
