@@ -18,44 +18,13 @@
 #include <algorithm>
 
 #include "pcf_common.h"
+#include "edge_mlp.h"
 
 namespace pcf {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY = 2, ACT_SIGMOID = 3 };
 
 constexpr int OC = 16;              // output channels handled per LDS round
 constexpr int MAXCH = 4;            // Cout <= 64
 constexpr int ZS = OC + 1;          // row stride of the per-wave [64 x 16] scratch tile (odd: conflict-free)
-
-struct RowLin {
-    const float* x;      // [R, Cin]
-    const float* dy;     // [R, Cout]            (backward)
-    float* y;            // [R, Cout]            (forward)
-    float* dx;           // [R, Cin] or null     (backward)
-    const float* W;      // [Cout, Cin]
-    const float* b;      // [Cout]
-    const float* mean;   // [Cout] or null (no BN)
-    const float* rstd;   // [Cout]
-    const float* gamma;  // [Cout]
-    const float* beta;   // [Cout]
-    const float* m1;     // [Cout] sum(g)/R          (backward apply, batch statistics)
-    const float* m2;     // [Cout] sum(g*xhat)/R
-    float* part;         // per-workgroup partial sums
-    long long R;
-    int Cin, Cout;
-    int batch_stats;     // backward: BN used batch statistics
-    int act;             // Act
-    // optional extras of the guidance first layer (Cout <= 16):
-    const float* gadd;       // [B*gN, Cout] per-point term gathered through gidx and added to x.W^T
-    const int64_t* gidx;     // [R] batch-local row of gadd for every row (out of range = no term)
-    float* dgadd;            // backward: [B*gN, Cout] float-atomic target (zeroed by the host wrapper)
-    long long rows_per_batch;
-    int gN;
-    int group;               // K (power of two <= 64): subtract the value of the group's first row; 0 = off
-    int vec_x, vec_y;    // 16-byte row access allowed
-};
 
 __device__ __forceinline__ float act_fwd(int ACT, float u) {
     if (ACT == ACT_RELU) return fmaxf(u, 0.f);
@@ -674,7 +643,8 @@ extern "C" {
 size_t pcf_hip_rowlin_workspace_bytes(int Cin, int Cout) {
     (void)Cout;
     const int CT = pcf::cin_template(Cin > 0 ? Cin : 1);
-    const size_t a = pcf::part_floats_stats(512), b = pcf::part_floats_apply(512, CT ? CT : 64);
+    // lane-per-row kernels: up to 512 workgroup partials; matrix-core kernels: up to 2048
+    const size_t a = pcf::part_floats_stats(2048), b = pcf::part_floats_apply(2048, CT ? CT : 64);
     return (std::max(a, b) + 4 * 64) * 4 + 256;
 }
 
@@ -711,9 +681,15 @@ int pcf_hip_rowlin_bn_stats_ex(const float* x, long long R, int Cin, const float
     a.part = static_cast<float*>(workspace);
     a.vec_x = (Cin % 4 == 0) && aligned16(x);
     int rc = PCF_OK;
-    PCF_CIN_SWITCH(CT, rc = launch_rowlin(rowlin_stats_kernel<C>, a, grid, lds_stats(C), s, "per-edge linear: BN statistics"));
+    int nparts = grid;
+    if (rowlin_mfma_supported(a)) {
+        nparts = rowlin_mfma_grid(R);
+        rc = rowlin_mfma_stats(a, nparts, s);
+    } else {
+        PCF_CIN_SWITCH(CT, rc = launch_rowlin(rowlin_stats_kernel<C>, a, grid, lds_stats(C), s, "per-edge linear: BN statistics"));
+    }
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(1), dim3(1024), 0, s, a.part, grid, R, Cout, eps, momentum,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(1), dim3(1024), 0, s, a.part, nparts, R, Cout, eps, momentum,
                        running_mean, running_var, mean_out, rstd_out);
     return check_launch("per-edge linear: BN finalize");
 }
@@ -743,6 +719,7 @@ int pcf_hip_rowlin_forward_ex(const float* x, long long R, int Cin, const float*
     a.vec_x = (Cin % 4 == 0) && aligned16(x);
     a.vec_y = (Cout % 4 == 0) && aligned16(y);
     int rc = PCF_OK;
+    if (rowlin_mfma_supported(a)) return rowlin_mfma_forward(a, (hipStream_t)stream);
     PCF_CIN_SWITCH(CT, rc = launch_rowlin(rowlin_fwd_kernel<C>, a, rowlin_grid(R), lds_fwd(C), (hipStream_t)stream,
                                           "per-edge linear forward"));
     return rc;
@@ -796,19 +773,23 @@ int pcf_hip_rowlin_backward_ex(const float* x, const float* dy, long long R, int
     a.vec_x = (Cin % 4 == 0) && aligned16(x) && (!dx || aligned16(dx));
     a.vec_y = (Cout % 4 == 0) && aligned16(dy);
     int rc = PCF_OK;
+    const bool mfma = rowlin_mfma_supported(a);
+    const int nparts = mfma ? rowlin_mfma_grid(R) : grid;
     if (bn) {
         // dgamma / dbeta (and, with batch statistics, the two means the dz formula needs)
-        PCF_CIN_SWITCH(CT, rc = launch_rowlin(rowlin_bwd_reduce_kernel<C>, a, grid, lds_stats(C), s,
-                                              "per-edge linear: BN backward reductions"));
+        if (mfma) rc = rowlin_mfma_bwd_reduce(a, nparts, s);
+        else PCF_CIN_SWITCH(CT, rc = launch_rowlin(rowlin_bwd_reduce_kernel<C>, a, grid, lds_stats(C), s,
+                                                   "per-edge linear: BN backward reductions"));
         if (rc) return rc;
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(1024), 0, s, part, grid, R, Cout, dgamma, dbeta, m1, m2);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(1024), 0, s, part, nparts, R, Cout, dgamma, dbeta, m1, m2);
         if (int e = check_launch("per-edge linear: BN backward finalize")) return e;
         a.m1 = m1; a.m2 = m2;
     }
-    PCF_CIN_SWITCH(CT, rc = launch_rowlin(rowlin_bwd_apply_kernel<C>, a, grid, lds_apply(C), s, "per-edge linear backward"));
+    if (mfma) rc = rowlin_mfma_bwd_apply(a, nparts, s);
+    else PCF_CIN_SWITCH(CT, rc = launch_rowlin(rowlin_bwd_apply_kernel<C>, a, grid, lds_apply(C), s, "per-edge linear backward"));
     if (rc) return rc;
-    const int PW = ((CT + 15) / 16) * 16;
-    hipLaunchKernelGGL(rowlin_param_reduce_kernel, dim3(ceil_div(Cout * Cin + Cout, 64)), dim3(BLOCK), 0, s, part, grid,
+    const int PW = mfma ? ((Cin + 15) / 16) * 16 : ((CT + 15) / 16) * 16;
+    hipLaunchKernelGGL(rowlin_param_reduce_kernel, dim3(ceil_div(Cout * Cin + Cout, 64)), dim3(BLOCK), 0, s, part, nparts,
                        PW, Cin, Cout, dW, db);
     return check_launch("per-edge linear: parameter-gradient reduction");
 }
