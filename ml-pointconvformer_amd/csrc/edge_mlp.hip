@@ -183,28 +183,26 @@ __global__ __launch_bounds__(BLOCK) void rowlin_stats_kernel(const RowLin a) {
     write_block_partials(s1, s2, red, a.part);
 }
 
-// Sum part[p][t] over p for the 128 statistics slots: 1024 threads = 8 slices x 128 slots, four
-// independent accumulators per thread so the loads pipeline, then an LDS combine in fp64.
-__device__ __forceinline__ double reduce_partials_128(const float* __restrict__ part, int nblocks, double* sh) {
-    const int t = threadIdx.x & 127, slice = threadIdx.x >> 7;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+// Sum the workgroup partials part[p][which*64 + c] over p for 8 channels x {sum, second sum} per
+// workgroup: 16 values x 64 slices of the partial list, two loads in flight per thread, fp64 combine.
+// Grid = 8 workgroups of 1024 threads covers the 64 channels.
+__device__ __forceinline__ void reduce_partials_8ch(const float* __restrict__ part, int nblocks, double (*sh)[16],
+                                                    double& sum0, double& sum1) {
+    const int v = threadIdx.x & 15, slice = threadIdx.x >> 4;          // v = which*8 + channel-in-block
+    const int col = (v >> 3) * 64 + blockIdx.x * 8 + (v & 7);
+    double a0 = 0.0, a1 = 0.0;
     int p = slice;
-    for (; p + 24 < nblocks; p += 32) {
-        a0 += (double)part[(size_t)p * 128 + t];
-        a1 += (double)part[(size_t)(p + 8) * 128 + t];
-        a2 += (double)part[(size_t)(p + 16) * 128 + t];
-        a3 += (double)part[(size_t)(p + 24) * 128 + t];
+    for (; p + 64 < nblocks; p += 128) {
+        a0 += (double)part[(size_t)p * 128 + col];
+        a1 += (double)part[(size_t)(p + 64) * 128 + col];
     }
-    for (; p < nblocks; p += 8) a0 += (double)part[(size_t)p * 128 + t];
-    sh[threadIdx.x] = (a0 + a1) + (a2 + a3);
+    for (; p < nblocks; p += 64) a0 += (double)part[(size_t)p * 128 + col];
+    sh[slice][v] = a0 + a1;
     __syncthreads();
-    double acc = 0.0;
-    if (threadIdx.x < 128) {
-#pragma unroll
-        for (int s = 0; s < 8; ++s) acc += sh[s * 128 + threadIdx.x];
+    sum0 = 0.0; sum1 = 0.0;
+    if (threadIdx.x < 8) {
+        for (int sl = 0; sl < 64; ++sl) { sum0 += sh[sl][threadIdx.x]; sum1 += sh[sl][8 + threadIdx.x]; }
     }
-    __syncthreads();
-    return acc;
 }
 
 // ---- K2: statistics -> mean, rstd, running-stat update --------------------------------------------
@@ -213,16 +211,14 @@ __global__ __launch_bounds__(1024) void bn_stats_finalize_kernel(const float* __
                                                                   float* __restrict__ running_mean,
                                                                   float* __restrict__ running_var,
                                                                   float* __restrict__ mean_out, float* __restrict__ rstd_out) {
-    __shared__ double sh[1024];
-    __shared__ double s[128];
-    const double acc = reduce_partials_128(part, nblocks, sh);
-    const int t = threadIdx.x;
-    if (t < 128) s[t] = acc;
-    __syncthreads();
-    if (t < Cout) {
+    __shared__ double sh[64][16];
+    double s0, s1;
+    reduce_partials_8ch(part, nblocks, sh, s0, s1);
+    const int t = blockIdx.x * 8 + threadIdx.x;
+    if (threadIdx.x < 8 && t < Cout) {
         const double n = (double)R;
-        const double mean = s[t] / n;
-        double var = s[64 + t] / n - mean * mean;
+        const double mean = s0 / n;
+        double var = s1 / n - mean * mean;
         if (var < 0.0) var = 0.0;
         mean_out[t] = (float)mean;
         rstd_out[t] = (float)(1.0 / sqrt(var + (double)eps));
@@ -361,13 +357,13 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
                                                                 int Cout, float* __restrict__ dgamma,
                                                                 float* __restrict__ dbeta, float* __restrict__ m1,
                                                                 float* __restrict__ m2) {
-    __shared__ double sh[1024];
-    const double acc = reduce_partials_128(part, nblocks, sh);
-    const int t = threadIdx.x;
-    const int o = t & 63;
-    if (t < 128 && o < Cout) {
-        if (t < 64) { dbeta[o] = (float)acc; m1[o] = (float)(acc / (double)R); }
-        else { dgamma[o] = (float)acc; m2[o] = (float)(acc / (double)R); }
+    __shared__ double sh[64][16];
+    double s0, s1;
+    reduce_partials_8ch(part, nblocks, sh, s0, s1);
+    const int o = blockIdx.x * 8 + threadIdx.x;
+    if (threadIdx.x < 8 && o < Cout) {
+        dbeta[o] = (float)s0; m1[o] = (float)(s0 / (double)R);
+        dgamma[o] = (float)s1; m2[o] = (float)(s1 / (double)R);
     }
 }
 
@@ -549,12 +545,12 @@ __global__ __launch_bounds__(BLOCK) void rowlin_bwd_apply_kernel(const RowLin a)
 }
 
 // ---- K7: sum the per-workgroup partials -> dW [Cout, Cin], db [Cout] ------------------------------
-// 64 outputs per workgroup x 4 slices of the partial list; consecutive lanes read consecutive
-// addresses of one partial, eight loads in flight per lane.
-__global__ __launch_bounds__(BLOCK) void rowlin_param_reduce_kernel(const float* __restrict__ part, int nblocks, int PW,
+// 64 outputs per workgroup x 16 slices of the partial list; consecutive lanes read consecutive addresses
+// of one partial, four loads in flight per lane; fixed combine order (deterministic).
+__global__ __launch_bounds__(1024) void rowlin_param_reduce_kernel(const float* __restrict__ part, int nblocks, int PW,
                                                                     int Cin, int Cout, float* __restrict__ dW,
                                                                     float* __restrict__ db) {
-    __shared__ float sh[BLOCK];
+    __shared__ float sh[16][64];
     const int total = Cout * Cin + Cout;
     const int stride = 64 * PW + 64;
     const int u = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -567,19 +563,21 @@ __global__ __launch_bounds__(BLOCK) void rowlin_param_reduce_kernel(const float*
         const float* q = part + src;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
         int p = slice;
-        for (; p + 12 < nblocks; p += 16) {
+        for (; p + 48 < nblocks; p += 64) {
             a0 += q[(size_t)p * stride];
-            a1 += q[(size_t)(p + 4) * stride];
-            a2 += q[(size_t)(p + 8) * stride];
-            a3 += q[(size_t)(p + 12) * stride];
+            a1 += q[(size_t)(p + 16) * stride];
+            a2 += q[(size_t)(p + 32) * stride];
+            a3 += q[(size_t)(p + 48) * stride];
         }
-        for (; p < nblocks; p += 4) a0 += q[(size_t)p * stride];
+        for (; p < nblocks; p += 16) a0 += q[(size_t)p * stride];
         acc = (a0 + a1) + (a2 + a3);
     }
-    sh[threadIdx.x] = acc;
+    sh[slice][threadIdx.x & 63] = acc;
     __syncthreads();
     if (threadIdx.x < 64 && u < total) {
-        const float v = (sh[threadIdx.x] + sh[64 + threadIdx.x]) + (sh[128 + threadIdx.x] + sh[192 + threadIdx.x]);
+        float v = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < 16; ++sl) v += sh[sl][threadIdx.x];
         if (u < Cout * Cin) dW[u] = v; else db[u - Cout * Cin] = v;
     }
 }
@@ -689,7 +687,7 @@ int pcf_hip_rowlin_bn_stats_ex(const float* x, long long R, int Cin, const float
         PCF_CIN_SWITCH(CT, rc = launch_rowlin(rowlin_stats_kernel<C>, a, grid, lds_stats(C), s, "per-edge linear: BN statistics"));
     }
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(1), dim3(1024), 0, s, a.part, nparts, R, Cout, eps, momentum,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(8), dim3(1024), 0, s, a.part, nparts, R, Cout, eps, momentum,
                        running_mean, running_var, mean_out, rstd_out);
     return check_launch("per-edge linear: BN finalize");
 }
@@ -781,7 +779,7 @@ int pcf_hip_rowlin_backward_ex(const float* x, const float* dy, long long R, int
         else PCF_CIN_SWITCH(CT, rc = launch_rowlin(rowlin_bwd_reduce_kernel<C>, a, grid, lds_stats(C), s,
                                                    "per-edge linear: BN backward reductions"));
         if (rc) return rc;
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(1024), 0, s, part, nparts, R, Cout, dgamma, dbeta, m1, m2);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(8), dim3(1024), 0, s, part, nparts, R, Cout, dgamma, dbeta, m1, m2);
         if (int e = check_launch("per-edge linear: BN backward finalize")) return e;
         a.m1 = m1; a.m2 = m2;
     }
@@ -789,7 +787,7 @@ int pcf_hip_rowlin_backward_ex(const float* x, const float* dy, long long R, int
     else PCF_CIN_SWITCH(CT, rc = launch_rowlin(rowlin_bwd_apply_kernel<C>, a, grid, lds_apply(C), s, "per-edge linear backward"));
     if (rc) return rc;
     const int PW = mfma ? ((Cin + 15) / 16) * 16 : ((CT + 15) / 16) * 16;
-    hipLaunchKernelGGL(rowlin_param_reduce_kernel, dim3(ceil_div(Cout * Cin + Cout, 64)), dim3(BLOCK), 0, s, part, nparts,
+    hipLaunchKernelGGL(rowlin_param_reduce_kernel, dim3(ceil_div(Cout * Cin + Cout, 64)), dim3(1024), 0, s, part, nparts,
                        PW, Cin, Cout, dW, db);
     return check_launch("per-edge linear: parameter-gradient reduction");
 }
