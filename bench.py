@@ -164,6 +164,9 @@ def main():
     ap.add_argument('--workload', choices=['layer', 'train'], default='layer')
     ap.add_argument('--scenes', type=int, default=4, help='scenes per GPU per iteration (train workload)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--graph', action='store_true',
+                    help='capture one step (forward+backward) in a HIP graph and time replays (1 GPU); the roofline '
+                         'kernel is then timed in eager steps right after the timed region')
     ap.add_argument('--deterministic', action='store_true',
                     help='grad_x by CSR gather-reduce (bitwise reproducible) instead of float atomics')
     args = ap.parse_args()
@@ -220,13 +223,30 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    eager_step = step
+    graph = None
+    if args.graph and world == 1:
+        # HIP graph of one whole step: ~90 kernel launches, memsets and allocations replayed with one call
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out_g, _ = model(xyz, feats, idx, nrm, None, None, None, inv_n, inv_k, inv_idx)
+            out_g.sum().backward()
+        step = graph.replay
+        for _ in range(3):
+            step()
 
     fence = lambda: pcf_dist.fence(dev)
 
     # HIP events around the launches of the aggregate kernels only (the roofline candidates): an event
     # pair per call on all ~45 entry points of a step would cost the host more than a millisecond.
     DOMINANT = ('pcf_hip_pcf_forward', 'pcf_hip_pcf_backward', 'pcf_hip_pcf_backward_csr')
-    timeline = pcf_cuda.record_kernel_times(True, only=DOMINANT)
+    timeline = pcf_cuda.record_kernel_times(graph is None, only=DOMINANT)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -234,6 +254,13 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     pcf_cuda.record_kernel_times(False)
+    step = eager_step
+    if graph is not None:          # events cannot bracket kernels inside a graph: time them in eager steps now
+        timeline = pcf_cuda.record_kernel_times(True, only=DOMINANT)
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        pcf_cuda.record_kernel_times(False)
     elapsed = pcf_dist.max_over_ranks(elapsed, dev)
 
     # device time of the bracketed entry points inside the timed region (events on the launch stream)
@@ -286,7 +313,7 @@ def main():
             'roofline': roofline,
             'hip_ms_per_call': {k: round(v, 4) for k, v in sorted(hip_ms_all.items())},
             'hip_ms_per_step': round(hip_total_ms, 4),
-            'knn_ms': round(knn_ms, 3), 'csr_ms': round(csr_ms, 3),
+            'knn_ms': round(knn_ms, 3), 'csr_ms': round(csr_ms, 3), 'hip_graph': graph is not None,
         }
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(layer.state_dict(), xyz, nrm, feats.detach(), idx)
