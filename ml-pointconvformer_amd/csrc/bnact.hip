@@ -51,15 +51,22 @@ __global__ __launch_bounds__(BLOCK) void col_partials_kernel(const float* __rest
         if (c < C) {
             float mu = 0.f, rs = 1.f, ga = 1.f, be = 0.f;
             if (MODE == 1 && mean) { mu = mean[c]; rs = rstd[c]; ga = gamma[c]; be = beta[c]; }
-            for (long long r = r0 + ty; r < r1; r += TY) {
+            auto term = [&](long long r, float& sa, float& sb) {
                 const float v = z[(size_t)r * C + c];
-                if (MODE == 0) { a += v; b += v * v; }
+                if (MODE == 0) { sa += v; sb += v * v; }
                 else {
                     const float xh = (v - mu) * rs;
                     const float g = dy[(size_t)r * C + c] * bn_act_bwd(act, mean ? xh * ga + be : v);
-                    a += g; b += g * xh;
+                    sa += g; sb += g * xh;
                 }
+            };
+            float a1 = 0.f, b1 = 0.f, a2 = 0.f, b2 = 0.f, a3 = 0.f, b3 = 0.f;
+            long long r = r0 + ty;
+            for (; r + 3 * TY < r1; r += 4 * TY) {      // four loads in flight per lane
+                term(r, a, b); term(r + TY, a1, b1); term(r + 2 * TY, a2, b2); term(r + 3 * TY, a3, b3);
             }
+            for (; r < r1; r += TY) term(r, a, b);
+            a = (a + a1) + (a2 + a3); b = (b + b1) + (b2 + b3);
         }
         s1[threadIdx.x] = a; s2[threadIdx.x] = b;
         __syncthreads();
@@ -72,27 +79,41 @@ __global__ __launch_bounds__(BLOCK) void col_partials_kernel(const float* __rest
     }
 }
 
-// combine partials: one workgroup per 64 columns x 4 slices of the partial list, fp64 accumulation
+// combine partials: one 1024-thread workgroup per 64 columns x 16 slices of the partial list, two
+// independent fp64 chains per slice and sum (a serial walk of ~300 partials is ~20 us of load latency)
+constexpr int FIN_THREADS = 1024;
+constexpr int FIN_SLICES = FIN_THREADS / 64;
 template <int MODE>
-__global__ __launch_bounds__(BLOCK) void col_finalize_kernel(const float* __restrict__ part, int nblocks, long long R, int C,
-                                                             float eps, float momentum, float* __restrict__ running_mean,
-                                                             float* __restrict__ running_var, float* __restrict__ o1,
-                                                             float* __restrict__ o2, float* __restrict__ m1,
-                                                             float* __restrict__ m2) {
-    __shared__ double sa[BLOCK], sb[BLOCK];
+__global__ __launch_bounds__(FIN_THREADS) void col_finalize_kernel(const float* __restrict__ part, int nblocks, long long R, int C,
+                                                                   float eps, float momentum, float* __restrict__ running_mean,
+                                                                   float* __restrict__ running_var, float* __restrict__ o1,
+                                                                   float* __restrict__ o2, float* __restrict__ m1,
+                                                                   float* __restrict__ m2) {
+    __shared__ double sa[FIN_THREADS], sb[FIN_THREADS];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int slice = threadIdx.x >> 6;
     double a = 0.0, b = 0.0;
-    if (c < C)
-        for (int p = slice; p < nblocks; p += 4) {
+    if (c < C) {
+        double a1 = 0.0, b1 = 0.0;
+        int p = slice;
+        for (; p + FIN_SLICES < nblocks; p += 2 * FIN_SLICES) {
+            a += (double)part[((size_t)p * 2 + 0) * C + c];
+            b += (double)part[((size_t)p * 2 + 1) * C + c];
+            a1 += (double)part[((size_t)(p + FIN_SLICES) * 2 + 0) * C + c];
+            b1 += (double)part[((size_t)(p + FIN_SLICES) * 2 + 1) * C + c];
+        }
+        if (p < nblocks) {
             a += (double)part[((size_t)p * 2 + 0) * C + c];
             b += (double)part[((size_t)p * 2 + 1) * C + c];
         }
+        a += a1; b += b1;
+    }
     sa[threadIdx.x] = a; sb[threadIdx.x] = b;
     __syncthreads();
     if (threadIdx.x < 64 && c < C) {
-        a = (sa[threadIdx.x] + sa[64 + threadIdx.x]) + (sa[128 + threadIdx.x] + sa[192 + threadIdx.x]);
-        b = (sb[threadIdx.x] + sb[64 + threadIdx.x]) + (sb[128 + threadIdx.x] + sb[192 + threadIdx.x]);
+        a = 0.0; b = 0.0;
+#pragma unroll
+        for (int sl = 0; sl < FIN_SLICES; ++sl) { a += sa[sl * 64 + threadIdx.x]; b += sb[sl * 64 + threadIdx.x]; }
         const double n = (double)R;
         if (MODE == 0) {
             const double mean = a / n;
@@ -114,20 +135,32 @@ __global__ __launch_bounds__(BLOCK) void col_finalize_kernel(const float* __rest
     }
 }
 
+// Per-column constants of the four consecutive columns a lane works on.  When the grid stride in elements
+// is a multiple of C (the host arranges that whenever C divides 4*BLOCK) they are loaded once per lane.
+struct Col4 { float mu[4], rs[4], ga[4], be[4]; };
+__device__ __forceinline__ void load_col4(Col4& k, int c, const float* mean, const float* rstd, const float* gamma,
+                                          const float* beta) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { k.mu[j] = mean[c + j]; k.rs[j] = rstd[c + j]; k.ga[j] = gamma[c + j]; k.be[j] = beta[c + j]; }
+}
+
 __global__ __launch_bounds__(BLOCK) void bnact_fwd_kernel(const float* __restrict__ z, float* __restrict__ y, long long total,
                                                           int C, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                          int act, int vec) {
+                                                          int act, int vec, int fixed_cols) {
     if (vec) {
         const long long units = total >> 2;
-        for (long long u = (long long)blockIdx.x * BLOCK + threadIdx.x; u < units; u += (long long)gridDim.x * BLOCK) {
-            const int c = (int)((u * 4) % C);
+        const long long u0 = (long long)blockIdx.x * BLOCK + threadIdx.x;
+        Col4 k;
+        if (mean && fixed_cols) load_col4(k, (int)((u0 * 4) % C), mean, rstd, gamma, beta);
+        for (long long u = u0; u < units; u += (long long)gridDim.x * BLOCK) {
+            if (mean && !fixed_cols) load_col4(k, (int)((u * 4) % C), mean, rstd, gamma, beta);
             float4 v = ld4(z + u * 4);
             float* e = &v.x;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float t = e[j];
-                if (mean) t = (t - mean[c + j]) * rstd[c + j] * gamma[c + j] + beta[c + j];
+                if (mean) t = (t - k.mu[j]) * k.rs[j] * k.ga[j] + k.be[j];
                 e[j] = bn_act_fwd(act, t);
             }
             st4(y + u * 4, v);
@@ -147,6 +180,7 @@ __global__ __launch_bounds__(BLOCK) void bnact_bwd_kernel(const float* __restric
                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           const float* __restrict__ m1, const float* __restrict__ m2, int act) {
+    // one element per lane and round: a float4 form of this kernel measured ~2x slower on gfx950 (31 vs 13 us at [80k, 64])
     for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (long long)gridDim.x * BLOCK) {
         const int c = (int)(i % C);
         const float v = z[i];
@@ -160,9 +194,15 @@ __global__ __launch_bounds__(BLOCK) void bnact_bwd_kernel(const float* __restric
     }
 }
 
-static int stats_blocks(long long R) { return (int)std::max<long long>(1, std::min<long long>((R + 255) / 256, 512)); }
+static int stats_blocks(long long R) { return (int)std::max<long long>(1, std::min<long long>((R + 127) / 128, 1024)); }
 static int tx_for(int C) { int t = 1; while (t < C && t < 64) t <<= 1; return t; }
-static int ew_grid(long long n) { return (int)std::max<long long>(1, std::min<long long>((n + BLOCK - 1) / BLOCK, 256 * 16)); }
+// element-wise grids: every workgroup runs the same number of grid-stride rounds (a capped grid with a ragged
+// last round leaves most of the chip idle for up to half of a short kernel)
+static int ew_grid(long long n) {
+    const long long need = std::max<long long>(1, (n + BLOCK - 1) / BLOCK), cap = 256 * 32;
+    const long long rounds = (need + cap - 1) / cap;
+    return (int)((need + rounds - 1) / rounds);
+}
 
 }  // namespace pcf
 
@@ -187,7 +227,7 @@ int pcf_hip_bnact_stats(const float* z, long long R, int C, float eps, float mom
     const long long rpb = (R + nb - 1) / nb;
     hipLaunchKernelGGL(col_partials_kernel<0>, dim3(nb), dim3(BLOCK), 0, s, z, nullptr, R, C, tx_for(C), rpb, nullptr, nullptr,
                        nullptr, nullptr, 0, part);
-    hipLaunchKernelGGL(col_finalize_kernel<0>, dim3(ceil_div(C, 64)), dim3(BLOCK), 0, s, part, nb, R, C, eps, momentum,
+    hipLaunchKernelGGL(col_finalize_kernel<0>, dim3(ceil_div(C, 64)), dim3(FIN_THREADS), 0, s, part, nb, R, C, eps, momentum,
                        running_mean, running_var, mean_out, rstd_out, nullptr, nullptr);
     return check_launch("bnact statistics");
 }
@@ -201,7 +241,7 @@ int pcf_hip_bnact_forward(const float* z, long long R, int C, const float* mean,
     const long long total = R * C;
     const int vec = (C % 4 == 0) && aligned16(z) && aligned16(y);
     hipLaunchKernelGGL(bnact_fwd_kernel, dim3(ew_grid(vec ? total / 4 : total)), dim3(BLOCK), 0, (hipStream_t)stream, z, y,
-                       total, C, mean, rstd, gamma, beta, act, vec);
+                       total, C, mean, rstd, gamma, beta, act, vec, (4 * BLOCK) % C == 0);
     return check_launch("bnact forward");
 }
 
@@ -229,13 +269,13 @@ int pcf_hip_bnact_backward(const float* z, const float* dy, long long R, int C, 
         const long long rpb = (R + nb - 1) / nb;
         hipLaunchKernelGGL(col_partials_kernel<1>, dim3(nb), dim3(BLOCK), 0, s, z, dy, R, C, tx_for(C), rpb, mean, rstd, gamma,
                            beta, act, part);
-        hipLaunchKernelGGL(col_finalize_kernel<1>, dim3(ceil_div(C, 64)), dim3(BLOCK), 0, s, part, nb, R, C, 0.f, 0.f, nullptr,
+        hipLaunchKernelGGL(col_finalize_kernel<1>, dim3(ceil_div(C, 64)), dim3(FIN_THREADS), 0, s, part, nb, R, C, 0.f, 0.f, nullptr,
                            nullptr, dbeta, dgamma, m1, m2);
         if (int e = check_launch("bnact backward reductions")) return e;
         if (!batch_stats) { m1 = nullptr; m2 = nullptr; }
     }
-    hipLaunchKernelGGL(bnact_bwd_kernel, dim3(ew_grid(R * C)), dim3(BLOCK), 0, s, z, dy, dz, R * C, C, mean, rstd, gamma, beta,
-                       m1, m2, act);
+    hipLaunchKernelGGL(bnact_bwd_kernel, dim3(std::min(ew_grid(R * C), 4096)), dim3(BLOCK), 0, s, z, dy, dz, R * C, C, mean,
+                       rstd, gamma, beta, m1, m2, act);
     return check_launch("bnact backward");
 }
 

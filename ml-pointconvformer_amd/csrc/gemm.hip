@@ -159,39 +159,63 @@ __global__ __launch_bounds__(BLOCK) void gemm_f32_kernel(const GemmArgs g) {
     }
 }
 
-// Sum split-K slabs: C[i] = sum_s slab[s][i] in a fixed order (deterministic).  Four slices of the slab
+// Sum split-K slabs: C[i] = sum_s slab[s][i] in a fixed order (deterministic).  SL slices of the slab
 // list per element, four loads in flight per lane.
-__global__ __launch_bounds__(BLOCK) void slab_sum_kernel(const float* __restrict__ slabs, float* __restrict__ C,
-                                                         long long count, int splits) {
-    __shared__ float sh[BLOCK];
+template <int SL>
+__global__ __launch_bounds__(64 * SL) void slab_sum_kernel(const float* __restrict__ slabs, float* __restrict__ C,
+                                                           long long count, int splits) {
+    __shared__ float sh[64 * SL];
     const long long i = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
     const int slice = threadIdx.x >> 6;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     if (i < count) {
         int s = slice;
-        for (; s + 12 < splits; s += 16) {
+        for (; s + 3 * SL < splits; s += 4 * SL) {
             a0 += slabs[(size_t)s * count + i];
-            a1 += slabs[(size_t)(s + 4) * count + i];
-            a2 += slabs[(size_t)(s + 8) * count + i];
-            a3 += slabs[(size_t)(s + 12) * count + i];
+            a1 += slabs[(size_t)(s + SL) * count + i];
+            a2 += slabs[(size_t)(s + 2 * SL) * count + i];
+            a3 += slabs[(size_t)(s + 3 * SL) * count + i];
         }
-        for (; s < splits; s += 4) a0 += slabs[(size_t)s * count + i];
+        for (; s < splits; s += SL) a0 += slabs[(size_t)s * count + i];
     }
     sh[threadIdx.x] = (a0 + a1) + (a2 + a3);
     __syncthreads();
-    if (threadIdx.x < 64 && i < count)
-        C[i] = (sh[threadIdx.x] + sh[64 + threadIdx.x]) + (sh[128 + threadIdx.x] + sh[192 + threadIdx.x]);
+    if (threadIdx.x < 64 && i < count) {
+        float t = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < SL; ++sl) t += sh[sl * 64 + threadIdx.x];
+        C[i] = t;
+    }
 }
 
-// Column sums of a [rows, cols] matrix in two deterministic stages (grad of the linear bias).
+// Column sums of a [rows, cols] matrix in two deterministic stages (grad of the linear bias).  A workgroup
+// owns a band of rows; its 256 threads are laid out TX columns x 256/TX row lanes so that narrow matrices
+// still use every lane, and the row lanes are combined through LDS in a fixed order.
 __global__ __launch_bounds__(BLOCK) void colsum_partial_kernel(const float* __restrict__ src, float* __restrict__ part,
-                                                               int rows, int cols, int rows_per_block) {
+                                                               int rows, int cols, int rows_per_block, int tx) {
+    __shared__ float sh[BLOCK];
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = min(rows, r0 + rows_per_block);
-    for (int c = threadIdx.x; c < cols; c += BLOCK) {
-        float acc = 0.f;
-        for (int r = r0; r < r1; ++r) acc += src[(size_t)r * cols + c];
-        part[(size_t)blockIdx.x * cols + c] = acc;
+    const int ty = BLOCK / tx, cx = threadIdx.x % tx, ry = threadIdx.x / tx;
+    for (int cb = 0; cb < cols; cb += tx) {
+        const int c = cb + cx;
+        float acc0 = 0.f, acc1 = 0.f;
+        if (c < cols) {
+            int r = r0 + ry;
+            for (; r + ty < r1; r += 2 * ty) {
+                acc0 += src[(size_t)r * cols + c];
+                acc1 += src[(size_t)(r + ty) * cols + c];
+            }
+            if (r < r1) acc0 += src[(size_t)r * cols + c];
+        }
+        sh[threadIdx.x] = acc0 + acc1;
+        __syncthreads();
+        if (ry == 0 && c < cols) {
+            float t = 0.f;
+            for (int j = 0; j < ty; ++j) t += sh[j * tx + cx];
+            part[(size_t)blockIdx.x * cols + c] = t;
+        }
+        __syncthreads();
     }
 }
 
@@ -231,13 +255,15 @@ int choose_splits(int M, int N, int Kd) {
     const long long tiles = (long long)ceil_div(M, N <= 32 ? 128 : 64) * ceil_div(N, N <= 32 ? 32 : 64);
     long long want = (1024 + tiles - 1) / tiles;             // ~4 workgroups per CU overall
     const long long max_by_k = std::max(1, Kd / (GBK * 8));  // at least 8 K-steps per split
-    return (int)std::max<long long>(1, std::min<long long>(std::min<long long>(want, max_by_k), 128));
+    return (int)std::max<long long>(1, std::min<long long>(std::min<long long>(want, max_by_k), 512));
 }
 
 int slab_sum(const float* slabs, float* C, long long count, int splits, hipStream_t s) {
     if (count == 0) return ok();
     const int grid = (int)((count + 63) / 64);
-    hipLaunchKernelGGL(slab_sum_kernel, dim3(grid), dim3(BLOCK), 0, s, slabs, C, count, splits);
+    // few elements, many slabs (bias gradients): spread the slab list over 16 waves of one workgroup
+    if (splits >= 64) hipLaunchKernelGGL(slab_sum_kernel<16>, dim3(grid), dim3(1024), 0, s, slabs, C, count, splits);
+    else hipLaunchKernelGGL(slab_sum_kernel<4>, dim3(grid), dim3(256), 0, s, slabs, C, count, splits);
     return check_launch("split-K slab sum");
 }
 
@@ -247,7 +273,9 @@ int colsum(const float* src, float* part, float* out, int rows, int cols, hipStr
     if (cols == 0) return ok();
     const int nb = colsum_blocks(rows);
     const int rpb = ceil_div(std::max(rows, 1), nb);
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(BLOCK), 0, s, src, part, rows, cols, rpb);
+    int tx = 1;
+    while (tx < cols && tx < BLOCK) tx <<= 1;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(BLOCK), 0, s, src, part, rows, cols, rpb, tx);
     if (int e = check_launch("bias-gradient partial sums")) return e;
     return slab_sum(part, out, cols, nb, s);
 }

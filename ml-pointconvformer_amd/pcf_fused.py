@@ -151,7 +151,11 @@ _gdiff_bwd = _sig('pcf_hip_guidance_diff_backward', [_P] * 5 + [_I] * 6 + [_P])
 
 
 def rowlin_supported(cin, cout):
-    return 1 <= cin <= ROWLIN_MAX_CHANNELS and 1 <= cout <= ROWLIN_MAX_CHANNELS
+    """Layers the fused row-linear kernels are the better choice for: both widths <= 64 and at most four
+    16x16 weight tiles (the matrix-core kernels keep W in registers); wider products go through the
+    contraction + column-wise BatchNorm kernels."""
+    return 1 <= cin <= ROWLIN_MAX_CHANNELS and 1 <= cout <= ROWLIN_MAX_CHANNELS \
+        and ((cin + 15) // 16) * ((cout + 15) // 16) <= 4
 
 
 class _LinearBNAct(torch.autograd.Function):
