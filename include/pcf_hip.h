@@ -244,6 +244,39 @@ int pcf_hip_guidance_diff_forward(const float* gx, const int64_t* idx, const flo
 int pcf_hip_guidance_diff_backward(const float* ds, const int64_t* idx, const uint8_t* argk, float* dgx, float* dpe,
                                    int B, int N, int M, int K, int G, int P, void* stream);
 
+/* ---- fused per-edge graph of a PCFLayer over self neighbourhoods ---------------------------------
+ * replaces, in ONE entry point per direction, the edge-level part of PCFLayer.forward (layers.py:361-384):
+ *   feat_pe = mlp_conv(VI)                                     Linear_BN(12 -> g) + ReLU        layers.py:361
+ *   score   = MultiHeadGuidance(cat(gathered guidance, feat_pe) - key)      two Linear_BN       layers.py:47-68,372-381
+ *   weights = WeightNet(VI)                                     three Linear_BN + ReLU           layers.py:163-171,384
+ * vi [E, cv] (E = B*M*K edges, cv <= 12), idx i64 [E] neighbour table, u [B*N, 8] = per-point half of the first
+ * guidance layer (see pcf_hip_rowlin_*_ex), rows_per_batch = M*K.  Layer order everywhere: mlp_conv, g1
+ * (positional half of its weight, [8, g]), g2, w1, w2, w3; hidden widths 8; g <= 32, heads <= 8, cm <= 16;
+ * K a power of two <= 16 and E % 16 == 0 (PCF_E_UNSUPPORTED otherwise: callers fall back to the
+ * layer-at-a-time entry points above).
+ * stats [12][64] floats on the device: mean of layer l at stats + 64*l, 1/sqrt(var+eps) at stats + 64*(6+l).
+ * forward, batch_stats != 0: statistics are computed (four recompute passes), written to stats and folded into
+ * the running statistics (nullable); batch_stats == 0: the caller provides them and only score / w are produced.
+ * pe, a1, h1, a2 (nullable) receive the intermediate activations [E, g], [E, 8], [E, 8], [E, 8]. */
+size_t pcf_hip_pcf_chain_workspace_bytes(void);
+int pcf_hip_pcf_chain_forward(const float* vi, const int64_t* idx, const float* u, long long E, long long rows_per_batch,
+                              int N, int K, int cv, int g, int heads, int cm, const float* const* W,
+                              const float* const* b, const float* const* gamma, const float* const* beta,
+                              float* const* running_mean, float* const* running_var, float eps, float momentum,
+                              int batch_stats, float* stats, float* pe, float* a1, float* h1, float* a2, float* score,
+                              float* w, void* workspace, size_t workspace_bytes, void* stream);
+/* Adjoint of the training-mode forward given dscore [E, heads], dw [E, cm] (from pcf_hip_pcf_backward) and the
+ * stats of the forward: du [B*N, 8] (zeroed here, float atomics) and, per layer, dW, db, dgamma, dbeta.
+ * Nothing per-edge is read but vi / idx / dscore / dw: the chain is recomputed in each of four passes.  db is
+ * written as zeros (a bias in front of a training-mode BatchNorm has an identically zero gradient). */
+size_t pcf_hip_pcf_chain_backward_workspace_bytes(void);
+int pcf_hip_pcf_chain_backward(const float* vi, const int64_t* idx, const float* u, const float* dscore, const float* dw,
+                               long long E, long long rows_per_batch, int N, int K, int cv, int g, int heads, int cm,
+                               const float* const* W, const float* const* b, const float* const* gamma,
+                               const float* const* beta, const float* stats, float* du, float* const* dW,
+                               float* const* db, float* const* dgamma, float* const* dbeta, void* workspace,
+                               size_t workspace_bytes, void* stream);
+
 /* ---- dense fp32 contraction used by the linear stage (exposed for tests / roofline) ----------
  * C[M,N] = A[M,Kd] . B^T  (+ bias[N] if bias != NULL), B given as [N,Kd] row-major.  MFMA f32. */
 int pcf_hip_gemm_nt(const float* A, const float* Bm, const float* bias, float* C, int M, int N, int Kd,

@@ -1,0 +1,59 @@
+// Shared declarations of the fused PCFLayer edge-graph kernels (edge_chain.hip forward, edge_chain_bwd.hip backward).
+#pragma once
+#include "pcf_common.h"
+
+namespace pcf {
+
+constexpr int CV = 12;     // max width of the WeightNet input (VI: 12, plain offsets: 3)
+constexpr int CG = 32;     // max width of the positional encoding (guidance_feat_len)
+constexpr int CH = 8;      // hidden width of the guidance MLP and of WeightNet
+constexpr int CHD = 8;     // max heads
+constexpr int CMX = 16;    // max C_mid
+
+enum { L_PE = 0, L_G1 = 1, L_G2 = 2, L_W1 = 3, L_W2 = 4, L_W3 = 5 };
+
+struct ChainArgs {
+    const float* vi;            // [E, cv]
+    const int64_t* idx;         // [E] batch-local neighbour index of every edge (for u)
+    const float* u;             // [B*N, 8]
+    long long E, rows_per_batch;
+    int N, K, cv, g, heads, cm;
+    const float* W[6];
+    const float* b[6];
+    const float* gamma[6];
+    const float* beta[6];
+    const float* mean[6];       // device [64] each; filled pass by pass
+    const float* rstd[6];
+    float* pe; float* a1; float* h1; float* a2; float* score; float* w;
+    float* part;                // [blocks][2][64] partial sums of the pass
+    int vec_vi;
+};
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- the chain on the matrix cores --------------------------------------------------------------------
+// Transposed formulation: for a tile of 16 edges, Z[o][p] = sum_c W[o][c] * Y[c][p] with
+// v_mfma_f32_16x16x4_f32 (exact fp32).  Accumulator layout (C/D map): lane l, register r holds
+// channel 4*(l>>4) + r of edge p = l & 15.  The B operand wants, for contraction step k = l>>4, one value
+// per lane of edge l & 15 -- so register s of the previous layer's accumulator IS the B operand of
+// contraction step s if that step is defined to cover channels {4k + s}: the contraction order is a free
+// choice as long as the weight fragment follows it (A[o][k] = W[o][4k + s]).  Hence
+//   * the six weight matrices live in 32 VGPRs for the whole kernel (loaded once),
+//   * a layer's output feeds the next layer with NO data movement (no LDS, no shuffles),
+//   * BatchNorm parameters are per-lane constants (channel 4*(l>>4)+r), statistics are per-lane running
+//     sums over tiles, reduced across the 16 edge lanes once at the end.
+// K <= 16 so a neighbourhood never straddles a tile (the key edge is lane l & ~(K-1) of the same group).
+__device__ __forceinline__ float wfrag(const float* W, int Cout, int Cin, int o, int c) {
+    return (W && o < Cout && c < Cin) ? W[o * Cin + c] : 0.f;
+}
+
+#define PCF_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_16x16x4f32((A), (B), (C), 0, 0, 0)
+
+// up to 4 workgroups per CU; every wave walks tiles with a grid stride
+inline int chain_grid(long long E) {
+    const long long tiles = E / 16;
+    const long long g = (tiles + NWAVE - 1) / NWAVE;
+    return (int)(g < 1 ? 1 : (g > 1024 ? 1024 : g));
+}
+
+}  // namespace pcf

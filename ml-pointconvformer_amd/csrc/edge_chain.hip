@@ -22,52 +22,9 @@
 // per edge at the BASELINE shape against ~2 kB for the layer-at-a-time path.
 #include <algorithm>
 
-#include "pcf_common.h"
+#include "edge_chain.h"
 
 namespace pcf {
-
-constexpr int CV = 12;     // max width of the WeightNet input (VI: 12, plain offsets: 3)
-constexpr int CG = 32;     // max width of the positional encoding (guidance_feat_len)
-constexpr int CH = 8;      // hidden width of the guidance MLP and of WeightNet
-constexpr int CHD = 8;     // max heads
-constexpr int CMX = 16;    // max C_mid
-
-enum { L_PE = 0, L_G1 = 1, L_G2 = 2, L_W1 = 3, L_W2 = 4, L_W3 = 5 };
-
-struct ChainArgs {
-    const float* vi;            // [E, cv]
-    const int64_t* idx;         // [E] batch-local neighbour index of every edge (for u)
-    const float* u;             // [B*N, 8]
-    long long E, rows_per_batch;
-    int N, K, cv, g, heads, cm;
-    const float* W[6];
-    const float* b[6];
-    const float* gamma[6];
-    const float* beta[6];
-    const float* mean[6];       // device [64] each; filled pass by pass
-    const float* rstd[6];
-    float* pe; float* a1; float* h1; float* a2; float* score; float* w;
-    float* part;                // [blocks][2][64] partial sums of the pass
-    int vec_vi;
-};
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-// ---- the chain on the matrix cores --------------------------------------------------------------------
-// Transposed formulation: for a tile of 16 edges, Z[o][p] = sum_c W[o][c] * Y[c][p] with
-// v_mfma_f32_16x16x4_f32 (exact fp32).  Accumulator layout (C/D map): lane l, register r holds
-// channel 4*(l>>4) + r of edge p = l & 15.  The B operand wants, for contraction step k = l>>4, one value
-// per lane of edge l & 15 -- so register s of the previous layer's accumulator IS the B operand of
-// contraction step s if that step is defined to cover channels {4k + s}: the contraction order is a free
-// choice as long as the weight fragment follows it (A[o][k] = W[o][4k + s]).  Hence
-//   * the six weight matrices live in 32 VGPRs for the whole kernel (loaded once),
-//   * a layer's output feeds the next layer with NO data movement (no LDS, no shuffles),
-//   * BatchNorm parameters are per-lane constants (channel 4*(l>>4)+r), statistics are per-lane running
-//     sums over tiles, reduced across the 16 edge lanes once at the end.
-// K <= 16 so a neighbourhood never straddles a tile (the key edge is lane l & ~(K-1) of the same group).
-__device__ __forceinline__ float wfrag(const float* W, int Cout, int Cin, int o, int c) {
-    return (W && o < Cout && c < Cin) ? W[o * Cin + c] : 0.f;
-}
 
 // BatchNorm constants of output-tile slot `f` (0 pe lo, 1 pe hi, 2 w1, 3 g1, 4 w2, 5 g2, 6 w3), channel c of the
 // tile: BN(acc + bias) = acc * scale + shift.  Kept in LDS ([slot][scale|shift][16]); a lane reads its four
@@ -101,8 +58,6 @@ __device__ __forceinline__ f32x4 bn_only(f32x4 v, const float (*cf)[16], int g) 
     v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y; v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
     return v;
 }
-
-#define PCF_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_16x16x4f32((A), (B), (C), 0, 0, 0)
 
 template <int LEVEL>
 __global__ __launch_bounds__(BLOCK) void pcf_chain_kernel(const ChainArgs a) {
@@ -333,12 +288,6 @@ __global__ __launch_bounds__(1024) void chain_finalize_kernel(const FinArgs f) {
     }
 }
 
-template <typename KernelT>
-static int chain_grid(KernelT, long long E) {
-    const long long tiles = E / 16;
-    return (int)std::max<long long>(1, std::min<long long>((tiles + NWAVE - 1) / NWAVE, 1024));    // 4 workgroups x 256 CUs
-}
-
 }  // namespace pcf
 
 extern "C" {
@@ -362,9 +311,8 @@ int pcf_hip_pcf_chain_forward(const float* vi, const int64_t* idx, const float* 
         return fail(PCF_E_UNSUPPORTED, "pcf_chain: K must be a power of two <= 16 and the edge count a multiple of 16 (K=%d)", K);
     if (E == 0) return ok();
     PCF_REQUIRE(vi && idx && u && W && b && gamma && beta && stats && score && w, "pcf_chain: null pointer");
-    PCF_REQUIRE(!batch_stats || (pe && a1 && h1 && a2), "pcf_chain: training needs the activation buffers");
     PCF_REQUIRE(aligned16(score) && aligned16(w) && aligned16(pe) && aligned16(a1) && aligned16(h1) && aligned16(a2) &&
-                    aligned16(u), "pcf_chain: buffers must be 16-byte aligned");
+                    aligned16(u), "pcf_chain: buffers must be 16-byte aligned");       // null activation pointers: not written
     PCF_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= pcf_hip_pcf_chain_workspace_bytes(),
                 "pcf_chain: workspace too small or misaligned");
     hipStream_t s = (hipStream_t)stream;
@@ -382,9 +330,9 @@ int pcf_hip_pcf_chain_forward(const float* vi, const int64_t* idx, const float* 
     if (batch_stats) {
         for (int pass = 0; pass < 3; ++pass) {
             int grid;
-            if (pass == 0) { grid = chain_grid(pcf_chain_kernel<1>, E); hipLaunchKernelGGL(pcf_chain_kernel<1>, dim3(grid), dim3(BLOCK), 0, s, a); }
-            else if (pass == 1) { grid = chain_grid(pcf_chain_kernel<2>, E); hipLaunchKernelGGL(pcf_chain_kernel<2>, dim3(grid), dim3(BLOCK), 0, s, a); }
-            else { grid = chain_grid(pcf_chain_kernel<3>, E); hipLaunchKernelGGL(pcf_chain_kernel<3>, dim3(grid), dim3(BLOCK), 0, s, a); }
+            if (pass == 0) { grid = chain_grid(E); hipLaunchKernelGGL(pcf_chain_kernel<1>, dim3(grid), dim3(BLOCK), 0, s, a); }
+            else if (pass == 1) { grid = chain_grid(E); hipLaunchKernelGGL(pcf_chain_kernel<2>, dim3(grid), dim3(BLOCK), 0, s, a); }
+            else { grid = chain_grid(E); hipLaunchKernelGGL(pcf_chain_kernel<3>, dim3(grid), dim3(BLOCK), 0, s, a); }
             if (int e = check_launch("pcf_chain pass")) return e;
             FinArgs f{};
             f.part = a.part; f.nblocks = grid; f.R = E; f.eps = eps; f.momentum = momentum;
@@ -401,7 +349,7 @@ int pcf_hip_pcf_chain_forward(const float* vi, const int64_t* idx, const float* 
             if (int e = check_launch("pcf_chain finalize")) return e;
         }
     }
-    hipLaunchKernelGGL(pcf_chain_kernel<4>, dim3(chain_grid(pcf_chain_kernel<4>, E)), dim3(BLOCK), 0, s, a);
+    hipLaunchKernelGGL(pcf_chain_kernel<4>, dim3(chain_grid(E)), dim3(BLOCK), 0, s, a);
     return check_launch("pcf_chain final pass");
 }
 

@@ -1,0 +1,514 @@
+// Fused backward of the per-edge graph of a PCFLayer (self neighbourhoods, training-mode BatchNorm) on gfx950.
+//
+// Adjoint of edge_chain.hip (layers.py:361-384, MultiHeadGuidance :47-68, WeightNet :163-171).  A BatchNorm in
+// training mode couples every edge: with g = dy * act'(.), xhat the normalised pre-activation,
+//     dz = gamma * rstd * (g - mean(g) - xhat * mean(g * xhat)),    dbeta = sum g,   dgamma = sum g * xhat
+// so layer l's dz needs two global sums that depend on the dz of the layer above it -- three dependent
+// reductions down each branch.  Layer-at-a-time execution (edge_mlp_mfma.hip) reads and writes every
+// [E, 8..32] activation and gradient twice per layer (~2 kB per edge).  Here nothing but the layer-graph inputs
+// is read: each of four passes RECOMPUTES the forward chain from the 48-byte VI row (as edge_chain.hip does) and
+// walks the gradient down to the first layer whose sums are still unknown:
+//     pass 1: sums of g2 and w3                                  (reads VI, idx/u, dscore, dw)
+//     pass 2: dz of g2, w3 -> dh1, da2;  sums of g1 and w2
+//     pass 3: dz of g1, w2 -> dpe, da1;  sums of mlp_conv and w1
+//     pass 4: every dz; the six dW (outer products on the matrix cores, operands transposed through LDS) and
+//             the gradient of the gathered term u (row-contiguous float atomics)
+// 4 x ~176 B read per edge and no per-edge write at all.  Bias gradients of a Linear that feeds a training-mode
+// BatchNorm are identically zero (the mean subtraction cancels them) and are written as zeros.
+//
+// Matrix-core formulation as in edge_chain.hip (transposed, 16 edges per tile, lane (p = l & 15, g = l >> 4)
+// holds channels 4g..4g+3 of edge p): backward products dIn[c][p] = sum_o W[o][c] dz[o][p] use the weight
+// fragment A[i = c][k <-> o = 4k + s], so a dz accumulator is again directly the B operand.  The 13 weight
+// fragments (8 forward, 5 transposed) and the BatchNorm constants live in LDS, not in registers.
+#include <algorithm>
+
+#include "edge_chain.h"
+
+namespace pcf {
+
+constexpr int TT = 17;              // row stride of the 16x16 transposition tiles
+constexpr int NFRAG = 13;
+constexpr int NSLOT = 7;            // output-tile slots: pe lo, pe hi, w1, g1, w2, g2, w3
+constexpr int NDW = 8;              // 16x16 weight-gradient tiles: pe lo, pe hi, w1, g1 (in lo), g1 (in hi), w2, g2, w3
+enum { K_RSTD = 0, K_X0 = 1, K_GAMMA = 2, K_BETA = 3, K_GM = 4, K_GXM = 5, NCONST = 6 };
+enum { S_PE0 = 0, S_PE1 = 1, S_W1 = 2, S_G1 = 3, S_W2 = 4, S_G2 = 5, S_W3 = 6 };
+
+struct ChainBwdArgs {
+    ChainArgs f;                // forward description (activation pointers unused)
+    const float* dscore;        // [E, heads]
+    const float* dw;            // [E, cm]
+    const float* gmean[6];      // mean over edges of g          (device [64] per layer, filled pass by pass)
+    const float* gxmean[6];     // mean over edges of g * xhat
+    float* du;                  // [B*N, 8], zeroed by the host; float atomics
+    float* part;                // pass partials
+};
+
+// constants of slot s, channel c of the tile
+__device__ __forceinline__ void stage_consts(const ChainBwdArgs& a, float (*cf)[NCONST][16], int level) {
+    const int layer_of[NSLOT] = {L_PE, L_PE, L_W1, L_G1, L_W2, L_G2, L_W3};
+    const int tile_of[NSLOT] = {0, 1, 0, 0, 0, 0, 0};
+    const int cout_of[NSLOT] = {a.f.g, a.f.g, CH, CH, CH, a.f.heads, a.f.cm};
+    const int need_level[NSLOT] = {4, 4, 4, 3, 3, 2, 2};          // the sums of slot s exist from this pass on
+    for (int t = threadIdx.x; t < NSLOT * 16; t += BLOCK) {
+        const int s = t >> 4, c = t & 15;
+        const int layer = layer_of[s], o = 16 * tile_of[s] + c;
+        float v[NCONST] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (o < cout_of[s]) {
+            v[K_RSTD] = a.f.rstd[layer][o];
+            v[K_X0] = (a.f.b[layer][o] - a.f.mean[layer][o]) * v[K_RSTD];
+            v[K_GAMMA] = a.f.gamma[layer][o];
+            v[K_BETA] = a.f.beta[layer][o];
+            if (level >= need_level[s]) { v[K_GM] = a.gmean[layer][o]; v[K_GXM] = a.gxmean[layer][o]; }
+        }
+#pragma unroll
+        for (int k = 0; k < NCONST; ++k) cf[s][k][c] = v[k];
+    }
+}
+
+// weight fragments by lane: wl[f][lane] = the four A-operand values (contraction steps s = 0..3) of fragment f
+__device__ __forceinline__ void stage_weights(const ChainBwdArgs& a, float4* wl) {
+    const ChainArgs& f = a.f;
+    for (int t = threadIdx.x; t < NFRAG * WAVE; t += BLOCK) {
+        const int fr = t / WAVE, l = t % WAVE, p = l & 15, g = l >> 4;
+        float v[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int k = 4 * g + s;
+            switch (fr) {
+                // forward: A[o = p][c = k]
+                case 0: v[s] = wfrag(f.W[L_PE], f.g, f.cv, p, k); break;
+                case 1: v[s] = wfrag(f.W[L_PE], f.g, f.cv, 16 + p, k); break;
+                case 2: v[s] = wfrag(f.W[L_W1], CH, f.cv, p, k); break;
+                case 3: v[s] = wfrag(f.W[L_G1], CH, f.g, p, k); break;
+                case 4: v[s] = wfrag(f.W[L_G1], CH, f.g, p, 16 + k); break;
+                case 5: v[s] = wfrag(f.W[L_W2], CH, CH, p, k); break;
+                case 6: v[s] = wfrag(f.W[L_G2], f.heads, CH, p, k); break;
+                case 7: v[s] = wfrag(f.W[L_W3], f.cm, CH, p, k); break;
+                // transposed: A[c = p][o = k]
+                case 8: v[s] = wfrag(f.W[L_G2], f.heads, CH, k, p); break;
+                case 9: v[s] = wfrag(f.W[L_W3], f.cm, CH, k, p); break;
+                case 10: v[s] = wfrag(f.W[L_G1], CH, f.g, k, p); break;
+                case 11: v[s] = wfrag(f.W[L_G1], CH, f.g, k, 16 + p); break;
+                default: v[s] = wfrag(f.W[L_W2], CH, CH, k, p); break;
+            }
+        }
+        wl[t] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+__device__ __forceinline__ f32x4 to_v4(float4 v) { return f32x4{v.x, v.y, v.z, v.w}; }
+
+// acc += W_fragment . operand  (four contraction steps)
+__device__ __forceinline__ f32x4 mm(const float4* wl, int frag, int lane, f32x4 operand, f32x4 acc) {
+    const f32x4 w = to_v4(wl[frag * WAVE + lane]);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = PCF_MFMA(w[s], operand[s], acc);
+    return acc;
+}
+
+// xhat of a raw accumulator tile (bias folded into x0)
+__device__ __forceinline__ f32x4 xhat_of(f32x4 acc, const float (*k)[16], int g) {
+    const f32x4 rs = to_v4(ld4(&k[K_RSTD][4 * g])), x0 = to_v4(ld4(&k[K_X0][4 * g]));
+    return acc * rs + x0;
+}
+__device__ __forceinline__ f32x4 pre_of(f32x4 xh, const float (*k)[16], int g) {
+    const f32x4 ga = to_v4(ld4(&k[K_GAMMA][4 * g])), be = to_v4(ld4(&k[K_BETA][4 * g]));
+    return xh * ga + be;
+}
+__device__ __forceinline__ f32x4 relu4(f32x4 v) {
+    return f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+}
+__device__ __forceinline__ f32x4 mask_pos(f32x4 d, f32x4 pre) {
+    return f32x4{pre[0] > 0.f ? d[0] : 0.f, pre[1] > 0.f ? d[1] : 0.f, pre[2] > 0.f ? d[2] : 0.f, pre[3] > 0.f ? d[3] : 0.f};
+}
+// dz = gamma * rstd * (g - mean g - xhat * mean(g xhat)); zero outside the layer's channels (constants are 0 there)
+__device__ __forceinline__ f32x4 bn_dz(f32x4 gr, f32x4 xh, const float (*k)[16], int g) {
+    const f32x4 rs = to_v4(ld4(&k[K_RSTD][4 * g])), ga = to_v4(ld4(&k[K_GAMMA][4 * g]));
+    const f32x4 gm = to_v4(ld4(&k[K_GM][4 * g])), gxm = to_v4(ld4(&k[K_GXM][4 * g]));
+    return ga * rs * (gr - gm - xh * gxm);
+}
+
+// one 16x16 tile [channel 4g+r][edge p] -> LDS [channel][edge]
+__device__ __forceinline__ void put_tile(float* buf, f32x4 v, int p, int g) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) buf[(4 * g + r) * TT + p] = v[r];
+}
+// dW tile += sum over the 16 edges of dz[o][e] * in[c][e]
+__device__ __forceinline__ f32x4 outer(const float* dzbuf, const float* inbuf, int p, int g, f32x4 acc) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = PCF_MFMA(dzbuf[p * TT + 4 * s + g], inbuf[p * TT + 4 * s + g], acc);
+    return acc;
+}
+
+template <int LEVEL>
+__global__ __launch_bounds__(BLOCK) void pcf_chain_bwd_kernel(const ChainBwdArgs a) {
+    __shared__ __align__(16) float cf[NSLOT][NCONST][16];
+    __shared__ float4 wl[NFRAG * WAVE];
+    __shared__ float red[LEVEL == 4 ? NDW * 256 : NWAVE * 96];
+    __shared__ float tbuf[LEVEL == 4 ? NWAVE * 5 * 16 * TT : 1];
+    __shared__ int gi[NWAVE][16];
+    const ChainArgs& f = a.f;
+    stage_consts(a, cf, LEVEL);
+    stage_weights(a, wl);
+    if (LEVEL == 4)
+        for (int t = threadIdx.x; t < NDW * 256; t += BLOCK) red[t] = 0.f;
+    __syncthreads();
+    const int lane = lane_id(), wave = wave_id();
+    const int p = lane & 15, g = lane >> 4;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 s1[3] = {zero4, zero4, zero4}, s2[3] = {zero4, zero4, zero4};
+    f32x4 accw[NDW];
+#pragma unroll
+    for (int i = 0; i < NDW; ++i) accw[i] = zero4;
+    const int lead = (lane & ~15) | (p & ~(f.K - 1));
+    const bool first = (p & (f.K - 1)) == 0;
+    const long long ntiles = f.E / 16;
+    const long long tstride = (long long)gridDim.x * NWAVE;
+    float* tb = LEVEL == 4 ? tbuf + wave * 5 * 16 * TT : tbuf;
+
+    auto load_x = [&](long long tt) -> f32x4 {
+        f32x4 xv = zero4;
+        if (tt < ntiles && 4 * g < f.cv) {
+            const float* q = f.vi + (size_t)(tt * 16 + p) * f.cv + 4 * g;
+            if (f.vec_vi) xv = to_v4(ld4(q));
+            else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xv[r] = (4 * g + r < f.cv) ? q[r] : 0.f;
+            }
+        }
+        return xv;
+    };
+    auto load_j = [&](long long tt) -> long long {
+        if (tt >= ntiles) return -1;
+        const int64_t j = f.idx[tt * 16 + p];
+        return (j >= 0 && j < f.N) ? (long long)((tt * 16 + p) / f.rows_per_batch) * f.N + j : -1;
+    };
+    auto load_u = [&](long long row) -> f32x4 {
+        return (row >= 0 && g < 2) ? to_v4(ld4(f.u + (size_t)row * CH + 4 * g)) : zero4;
+    };
+    auto load_grad = [&](const float* base, long long tt, int C) -> f32x4 {
+        f32x4 v = zero4;
+        if (4 * g < C) {
+            const float* q = base + (size_t)(tt * 16 + p) * C + 4 * g;
+            if ((C & 3) == 0) v = to_v4(ld4(q));
+            else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = (4 * g + r < C) ? q[r] : 0.f;
+            }
+        }
+        return v;
+    };
+
+    long long t = (long long)blockIdx.x * NWAVE + wave;
+    f32x4 x = load_x(t), x_next = load_x(t + tstride);
+    long long j_cur = load_j(t);
+    f32x4 ucur = load_u(j_cur);
+    long long j_next = load_j(t + tstride);
+    for (; t < ntiles; t += tstride) {
+        asm volatile("" ::: "memory");          // LDS-resident weights / constants are re-read per tile, not hoisted into VGPRs
+        // prefetch: gathered u row of tile t+1, index and input of tile t+2, upstream gradients of this tile
+        const f32x4 u_next = load_u(j_next);
+        const long long j_nn = load_j(t + 2 * tstride);
+        const f32x4 x_nn = load_x(t + 2 * tstride);
+        const f32x4 dsc = load_grad(a.dscore, t, f.heads);
+        const f32x4 dwv = load_grad(a.dw, t, f.cm);
+
+        // ---- forward, keeping xhat of every layer ----
+        const f32x4 xh_pe0 = xhat_of(mm(wl, 0, lane, x, zero4), cf[S_PE0], g);
+        const f32x4 xh_pe1 = xhat_of(mm(wl, 1, lane, x, zero4), cf[S_PE1], g);
+        const f32x4 xh_a1 = xhat_of(mm(wl, 2, lane, x, zero4), cf[S_W1], g);
+        const f32x4 y_pe0 = relu4(pre_of(xh_pe0, cf[S_PE0], g));
+        const f32x4 y_pe1 = relu4(pre_of(xh_pe1, cf[S_PE1], g));
+        const f32x4 y_a1 = relu4(pre_of(xh_a1, cf[S_W1], g));
+        f32x4 h1 = mm(wl, 3, lane, y_pe0, zero4);
+        const f32x4 h1b = mm(wl, 4, lane, y_pe1, zero4);
+        const f32x4 xh_a2 = xhat_of(mm(wl, 5, lane, y_a1, zero4), cf[S_W2], g);
+        h1 = h1 + h1b + ucur;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h1[r] -= __shfl(h1[r], lead, WAVE);
+        const f32x4 xh_h1 = xhat_of(h1, cf[S_G1], g);
+        const f32x4 y_h1 = relu4(pre_of(xh_h1, cf[S_G1], g));
+        const f32x4 y_a2 = relu4(pre_of(xh_a2, cf[S_W2], g));
+        const f32x4 xh_sc = xhat_of(mm(wl, 6, lane, y_h1, zero4), cf[S_G2], g);
+        const f32x4 xh_w = xhat_of(mm(wl, 7, lane, y_a2, zero4), cf[S_W3], g);
+        const f32x4 pre_sc = pre_of(xh_sc, cf[S_G2], g);
+        const f32x4 pre_w = pre_of(xh_w, cf[S_W3], g);
+
+        // ---- top of the backward: g of g2 (sigmoid) and w3 (ReLU) ----
+        f32x4 g_sc, g_w = mask_pos(dwv, pre_w);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float sg = 1.f / (1.f + __expf(-pre_sc[r]));
+            g_sc[r] = dsc[r] * sg * (1.f - sg);
+        }
+        if (LEVEL == 1) {
+            s1[0] += g_sc; s2[0] += g_sc * xh_sc;
+            s1[1] += g_w;  s2[1] += g_w * xh_w;
+            x = x_next; x_next = x_nn; ucur = u_next; j_cur = j_next; j_next = j_nn;
+            continue;
+        }
+        const f32x4 dz_sc = bn_dz(g_sc, xh_sc, cf[S_G2], g);
+        const f32x4 dz_w = bn_dz(g_w, xh_w, cf[S_W3], g);
+        if (LEVEL == 4) {
+            put_tile(tb + 0 * 16 * TT, dz_sc, p, g);
+            put_tile(tb + 1 * 16 * TT, y_h1, p, g);
+            put_tile(tb + 2 * 16 * TT, dz_w, p, g);
+            put_tile(tb + 3 * 16 * TT, y_a2, p, g);
+            accw[6] = outer(tb + 0 * 16 * TT, tb + 1 * 16 * TT, p, g, accw[6]);
+            accw[7] = outer(tb + 2 * 16 * TT, tb + 3 * 16 * TT, p, g, accw[7]);
+        }
+        const f32x4 g_h1 = mask_pos(mm(wl, 8, lane, dz_sc, zero4), y_h1);
+        const f32x4 g_a2 = mask_pos(mm(wl, 9, lane, dz_w, zero4), y_a2);
+        if (LEVEL == 2) {
+            s1[0] += g_h1; s2[0] += g_h1 * xh_h1;
+            s1[1] += g_a2; s2[1] += g_a2 * xh_a2;
+            x = x_next; x_next = x_nn; ucur = u_next; j_cur = j_next; j_next = j_nn;
+            continue;
+        }
+        f32x4 dq = bn_dz(g_h1, xh_h1, cf[S_G1], g);
+        const f32x4 dz_a2 = bn_dz(g_a2, xh_a2, cf[S_W2], g);
+        // z[k] = q[k] - q[key] + b  =>  dq[k] = dz[k] - [k is the key] * (sum over the neighbourhood)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float tot = dq[r];
+            for (int off = 1; off < f.K; off <<= 1) tot += __shfl_xor(tot, off, WAVE);
+            if (first) dq[r] -= tot;
+        }
+        if (LEVEL == 4) {
+            put_tile(tb + 0 * 16 * TT, dq, p, g);
+            put_tile(tb + 1 * 16 * TT, y_pe0, p, g);
+            put_tile(tb + 2 * 16 * TT, y_pe1, p, g);
+            put_tile(tb + 3 * 16 * TT, dz_a2, p, g);
+            put_tile(tb + 4 * 16 * TT, y_a1, p, g);
+            // gradient of the gathered term: consecutive lanes cover the 8 consecutive channels of one row of du
+            if (g == 0) gi[wave][p] = (int)j_cur;
+            for (int e = lane; e < 16 * CH; e += WAVE) {
+                const int r = e / CH, o = e - r * CH;
+                const int tgt = gi[wave][r];
+                if (tgt >= 0) atomicAdd(a.du + (size_t)tgt * CH + o, tb[o * TT + r]);
+            }
+            accw[3] = outer(tb + 0 * 16 * TT, tb + 1 * 16 * TT, p, g, accw[3]);
+            accw[4] = outer(tb + 0 * 16 * TT, tb + 2 * 16 * TT, p, g, accw[4]);
+            accw[5] = outer(tb + 3 * 16 * TT, tb + 4 * 16 * TT, p, g, accw[5]);
+        }
+        const f32x4 g_pe0 = mask_pos(mm(wl, 10, lane, dq, zero4), y_pe0);
+        const f32x4 g_pe1 = mask_pos(mm(wl, 11, lane, dq, zero4), y_pe1);
+        const f32x4 g_a1 = mask_pos(mm(wl, 12, lane, dz_a2, zero4), y_a1);
+        if (LEVEL == 3) {
+            s1[0] += g_pe0; s2[0] += g_pe0 * xh_pe0;
+            s1[1] += g_pe1; s2[1] += g_pe1 * xh_pe1;
+            s1[2] += g_a1;  s2[2] += g_a1 * xh_a1;
+            x = x_next; x_next = x_nn; ucur = u_next; j_cur = j_next; j_next = j_nn;
+            continue;
+        }
+        if (LEVEL == 4) {
+            put_tile(tb + 0 * 16 * TT, bn_dz(g_pe0, xh_pe0, cf[S_PE0], g), p, g);
+            put_tile(tb + 1 * 16 * TT, bn_dz(g_pe1, xh_pe1, cf[S_PE1], g), p, g);
+            put_tile(tb + 2 * 16 * TT, bn_dz(g_a1, xh_a1, cf[S_W1], g), p, g);
+            put_tile(tb + 3 * 16 * TT, x, p, g);
+            accw[0] = outer(tb + 0 * 16 * TT, tb + 3 * 16 * TT, p, g, accw[0]);
+            accw[1] = outer(tb + 1 * 16 * TT, tb + 3 * 16 * TT, p, g, accw[1]);
+            accw[2] = outer(tb + 2 * 16 * TT, tb + 3 * 16 * TT, p, g, accw[2]);
+        }
+        x = x_next; x_next = x_nn; ucur = u_next; j_cur = j_next; j_next = j_nn;
+    }
+
+    if (LEVEL == 4) {
+        // combine the four waves in wave order (deterministic): red[tile][o][c]
+        for (int wv = 0; wv < NWAVE; ++wv) {
+            if (wave == wv) {
+#pragma unroll
+                for (int i = 0; i < NDW; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red[i * 256 + (4 * g + r) * 16 + p] += accw[i][r];
+            }
+            __syncthreads();
+        }
+        float* outp = a.part + (size_t)blockIdx.x * (NDW * 256);
+        for (int u = threadIdx.x; u < NDW * 256; u += BLOCK) outp[u] = red[u];
+        return;
+    }
+    // per-lane sums -> per-channel sums over the 16 edge lanes; lane p == 0 of group g owns channels 4g..4g+3
+    float (*rw)[3][2][16] = reinterpret_cast<float (*)[3][2][16]>(red);
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v1 = s1[q][r], v2 = s2[q][r];
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) { v1 += __shfl_xor(v1, off, WAVE); v2 += __shfl_xor(v2, off, WAVE); }
+            if (p == 0) { rw[wave][q][0][4 * g + r] = v1; rw[wave][q][1][4 * g + r] = v2; }
+        }
+    __syncthreads();
+    if (threadIdx.x < 96) {
+        const int q = threadIdx.x / 32, which = (threadIdx.x >> 4) & 1, c = threadIdx.x & 15;
+        float tsum = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWAVE; ++w) tsum += rw[w][q][which][c];
+        a.part[(size_t)blockIdx.x * 96 + threadIdx.x] = tsum;
+    }
+}
+
+// Sums of one pass: up to three groups of 16 channels, each a slice [chan0, chan0 + count) of one layer.
+struct BwdFinGroup { float* dbeta; float* dgamma; float* gmean; float* gxmean; int chan0; int count; };
+struct BwdFinArgs { BwdFinGroup g[3]; const float* part; int nblocks; long long R; };
+
+__global__ __launch_bounds__(1024) void chain_bwd_finalize_kernel(const BwdFinArgs f) {
+    __shared__ double sh[10][96];
+    const int v = threadIdx.x % 96, slice = threadIdx.x / 96;
+    if (slice < 10) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int p = slice;
+        for (; p + 30 < f.nblocks; p += 40) {
+            a0 += (double)f.part[(size_t)p * 96 + v];
+            a1 += (double)f.part[(size_t)(p + 10) * 96 + v];
+            a2 += (double)f.part[(size_t)(p + 20) * 96 + v];
+            a3 += (double)f.part[(size_t)(p + 30) * 96 + v];
+        }
+        for (; p < f.nblocks; p += 10) a0 += (double)f.part[(size_t)p * 96 + v];
+        sh[slice][v] = (a0 + a1) + (a2 + a3);
+    }
+    __syncthreads();
+    if (threadIdx.x < 48) {
+        const int q = threadIdx.x >> 4, c = threadIdx.x & 15;
+        double sums[2] = {0.0, 0.0};
+#pragma unroll
+        for (int which = 0; which < 2; ++which)
+#pragma unroll
+            for (int sl = 0; sl < 10; ++sl) sums[which] += sh[sl][q * 32 + which * 16 + c];
+        const BwdFinGroup& g = f.g[q];
+        if (g.dbeta && c < g.count) {
+            const int o = g.chan0 + c;
+            g.dbeta[o] = (float)sums[0];
+            g.dgamma[o] = (float)sums[1];
+            g.gmean[o] = (float)(sums[0] / (double)f.R);
+            g.gxmean[o] = (float)(sums[1] / (double)f.R);
+        }
+    }
+}
+
+// dW of the six layers from the per-workgroup 16x16 tiles of pass 4; one workgroup per 64 tile elements,
+// 16 slices of the partial list each (fixed order).
+struct BwdParamArgs {
+    const float* part; int nblocks;
+    float* dW[6];
+    int cv, g, heads, cm;
+};
+
+__global__ __launch_bounds__(1024) void chain_bwd_params_kernel(const BwdParamArgs f) {
+    __shared__ float sh[16][64];
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63);        // element of the [NDW][16][16] tile set
+    const int slice = threadIdx.x >> 6;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int p = slice;
+    for (; p + 48 < f.nblocks; p += 64) {
+        a0 += f.part[(size_t)p * (NDW * 256) + e];
+        a1 += f.part[(size_t)(p + 16) * (NDW * 256) + e];
+        a2 += f.part[(size_t)(p + 32) * (NDW * 256) + e];
+        a3 += f.part[(size_t)(p + 48) * (NDW * 256) + e];
+    }
+    for (; p < f.nblocks; p += 16) a0 += f.part[(size_t)p * (NDW * 256) + e];
+    sh[slice][threadIdx.x & 63] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    float tot = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < 16; ++sl) tot += sh[sl][threadIdx.x];
+    const int tile = e >> 8, o = (e >> 4) & 15, c = e & 15;
+    switch (tile) {
+        case 0: if (o < f.g && c < f.cv) f.dW[L_PE][o * f.cv + c] = tot; break;
+        case 1: if (16 + o < f.g && c < f.cv) f.dW[L_PE][(16 + o) * f.cv + c] = tot; break;
+        case 2: if (o < CH && c < f.cv) f.dW[L_W1][o * f.cv + c] = tot; break;
+        case 3: if (o < CH && c < f.g) f.dW[L_G1][o * f.g + c] = tot; break;
+        case 4: if (o < CH && 16 + c < f.g) f.dW[L_G1][o * f.g + 16 + c] = tot; break;
+        case 5: if (o < CH && c < CH) f.dW[L_W2][o * CH + c] = tot; break;
+        case 6: if (o < f.heads && c < CH) f.dW[L_G2][o * CH + c] = tot; break;
+        default: if (o < f.cm && c < CH) f.dW[L_W3][o * CH + c] = tot; break;
+    }
+}
+
+}  // namespace pcf
+
+extern "C" {
+
+size_t pcf_hip_pcf_chain_backward_workspace_bytes(void) {
+    return ((size_t)1024 * pcf::NDW * 256 + 12 * 64) * 4 + 1024;
+}
+
+int pcf_hip_pcf_chain_backward(const float* vi, const int64_t* idx, const float* u, const float* dscore, const float* dw,
+                               long long E, long long rows_per_batch, int N, int K, int cv, int g, int heads, int cm,
+                               const float* const* W, const float* const* b, const float* const* gamma,
+                               const float* const* beta, const float* stats, float* du, float* const* dW, float* const* db,
+                               float* const* dgamma, float* const* dbeta, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+    using namespace pcf;
+    PCF_REQUIRE(E >= 0 && rows_per_batch > 0 && N >= 0, "pcf_chain_backward: bad sizes");
+    if (cv < 1 || cv > CV || g < 1 || g > CG || heads < 1 || heads > CHD || cm < 1 || cm > CMX)
+        return fail(PCF_E_UNSUPPORTED, "pcf_chain_backward: widths outside the fused kernel (cv=%d<=12, g=%d<=32, heads=%d<=8, cm=%d<=16)", cv, g, heads, cm);
+    if (K < 1 || K > 16 || (K & (K - 1)) != 0 || E % 16 != 0 || E % rows_per_batch != 0)
+        return fail(PCF_E_UNSUPPORTED, "pcf_chain_backward: K must be a power of two <= 16 and the edge count a multiple of 16 (K=%d)", K);
+    PCF_REQUIRE(W && b && gamma && beta && stats && du && dW && db && dgamma && dbeta, "pcf_chain_backward: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int couts[6] = {g, CH, heads, CH, CH, cm};
+    const int cins[6] = {cv, g, CH, cv, CH, CH};
+    for (int l = 0; l < 6; ++l) {
+        PCF_REQUIRE(W[l] && b[l] && gamma[l] && beta[l] && dW[l] && db[l] && dgamma[l] && dbeta[l],
+                    "pcf_chain_backward: null parameter of layer %d", l);
+        // bias before a training-mode BatchNorm: the gradient is identically zero
+        if (hipMemsetAsync(db[l], 0, (size_t)couts[l] * 4, s) != hipSuccess) return fail(PCF_E_LAUNCH, "pcf_chain_backward: memset");
+        if (E == 0) {
+            (void)hipMemsetAsync(dW[l], 0, (size_t)couts[l] * cins[l] * 4, s);
+            (void)hipMemsetAsync(dgamma[l], 0, (size_t)couts[l] * 4, s);
+            (void)hipMemsetAsync(dbeta[l], 0, (size_t)couts[l] * 4, s);
+        }
+    }
+    const long long batches = E / rows_per_batch;
+    if (batches * N > 0 && hipMemsetAsync(du, 0, (size_t)batches * N * CH * 4, s) != hipSuccess)
+        return fail(PCF_E_LAUNCH, "pcf_chain_backward: memset");
+    if (E == 0) return ok();
+    PCF_REQUIRE(vi && idx && u && dscore && dw, "pcf_chain_backward: null pointer");
+    PCF_REQUIRE(aligned16(u) && aligned16(dscore) && aligned16(dw) && aligned16(du), "pcf_chain_backward: buffers must be 16-byte aligned");
+    PCF_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= pcf_hip_pcf_chain_backward_workspace_bytes(),
+                "pcf_chain_backward: workspace too small or misaligned");
+    PCF_REQUIRE(batches * N < (1ll << 31), "pcf_chain_backward: too many points");
+    ChainBwdArgs a{};
+    a.f.vi = vi; a.f.idx = idx; a.f.u = u; a.f.E = E; a.f.rows_per_batch = rows_per_batch; a.f.N = N; a.f.K = K;
+    a.f.cv = cv; a.f.g = g; a.f.heads = heads; a.f.cm = cm;
+    a.f.vec_vi = (cv % 4 == 0) && aligned16(vi);
+    float* means = static_cast<float*>(workspace);           // [12][64]: mean g, then mean g*xhat, per layer
+    a.part = means + 12 * 64;
+    for (int l = 0; l < 6; ++l) {
+        a.f.W[l] = W[l]; a.f.b[l] = b[l]; a.f.gamma[l] = gamma[l]; a.f.beta[l] = beta[l];
+        a.f.mean[l] = stats + l * 64; a.f.rstd[l] = stats + (6 + l) * 64;
+        a.gmean[l] = means + l * 64; a.gxmean[l] = means + (6 + l) * 64;
+    }
+    a.dscore = dscore; a.dw = dw; a.du = du;
+    const int grid = chain_grid(E);
+    for (int pass = 0; pass < 3; ++pass) {
+        if (pass == 0) hipLaunchKernelGGL(pcf_chain_bwd_kernel<1>, dim3(grid), dim3(BLOCK), 0, s, a);
+        else if (pass == 1) hipLaunchKernelGGL(pcf_chain_bwd_kernel<2>, dim3(grid), dim3(BLOCK), 0, s, a);
+        else hipLaunchKernelGGL(pcf_chain_bwd_kernel<3>, dim3(grid), dim3(BLOCK), 0, s, a);
+        if (int e = check_launch("pcf_chain_backward pass")) return e;
+        BwdFinArgs fa{};
+        fa.part = a.part; fa.nblocks = grid; fa.R = E;
+        auto set = [&](int q, int layer, int chan0, int count) {
+            fa.g[q].dbeta = dbeta[layer]; fa.g[q].dgamma = dgamma[layer];
+            fa.g[q].gmean = means + layer * 64; fa.g[q].gxmean = means + (6 + layer) * 64;
+            fa.g[q].chan0 = chan0; fa.g[q].count = count;
+        };
+        if (pass == 0) { set(0, L_G2, 0, heads); set(1, L_W3, 0, cm); }
+        else if (pass == 1) { set(0, L_G1, 0, CH); set(1, L_W2, 0, CH); }
+        else { set(0, L_PE, 0, std::min(g, 16)); set(1, L_PE, 16, std::max(g - 16, 0)); set(2, L_W1, 0, CH); }
+        hipLaunchKernelGGL(chain_bwd_finalize_kernel, dim3(1), dim3(1024), 0, s, fa);
+        if (int e = check_launch("pcf_chain_backward finalize")) return e;
+    }
+    hipLaunchKernelGGL(pcf_chain_bwd_kernel<4>, dim3(grid), dim3(BLOCK), 0, s, a);
+    if (int e = check_launch("pcf_chain_backward final pass")) return e;
+    BwdParamArgs pa{};
+    pa.part = a.part; pa.nblocks = grid; pa.cv = cv; pa.g = g; pa.heads = heads; pa.cm = cm;
+    for (int l = 0; l < 6; ++l) pa.dW[l] = dW[l];
+    hipLaunchKernelGGL(chain_bwd_params_kernel, dim3(NDW * 256 / 64), dim3(1024), 0, s, pa);
+    return check_launch("pcf_chain_backward parameter reduction");
+}
+
+}  // extern "C"

@@ -394,6 +394,14 @@ _chain_fwd = _sig('pcf_hip_pcf_chain_forward',
                    _P, _P, _P, _P, _P, _P, _P, _Z, _P])
 
 
+_chain_bwd_ws = getattr(_lib, 'pcf_hip_pcf_chain_backward_workspace_bytes')
+_chain_bwd_ws.argtypes = []
+_chain_bwd_ws.restype = _Z
+_chain_bwd = _sig('pcf_hip_pcf_chain_backward',
+                  [_P, _P, _P, _P, _P, _LL, _LL, _I, _I, _I, _I, _I, _I, _PP, _PP, _PP, _PP, _P, _P, _PP, _PP, _PP, _PP,
+                   _P, _Z, _P])
+
+
 def _ptr_array(tensors):
     arr = (ctypes.c_void_p * len(tensors))()
     for i, t in enumerate(tensors):
@@ -428,7 +436,7 @@ class _PCFChain(torch.autograd.Function):
     (running statistics are updated in place in training)."""
 
     @staticmethod
-    def forward(ctx, idx, bns, training, vi, u, fx, *params):
+    def forward(ctx, idx, bns, training, fused_backward, vi, u, fx, *params):
         dev = vi.device
         B, M, K, cv = vi.shape
         N = u.shape[1]
@@ -446,8 +454,9 @@ class _PCFChain(torch.autograd.Function):
         w = torch.empty(B, M, K, cm, **f32)
         pe = a1 = h1 = a2 = None
         if training:
-            pe, a1 = torch.empty(B, M, K, g, **f32), torch.empty(B, M, K, 8, **f32)
-            h1, a2 = torch.empty(B, M, K, 8, **f32), torch.empty(B, M, K, 8, **f32)
+            if not fused_backward:      # the layer-at-a-time backward reads the intermediate activations
+                pe, a1 = torch.empty(B, M, K, g, **f32), torch.empty(B, M, K, 8, **f32)
+                h1, a2 = torch.empty(B, M, K, 8, **f32), torch.empty(B, M, K, 8, **f32)
             for bn in bns:
                 if bn.num_batches_tracked is not None:
                     bn.num_batches_tracked += 1
@@ -466,17 +475,31 @@ class _PCFChain(torch.autograd.Function):
         agg = pcf_cuda.pcf_forward(fx, idx, score, w)
         ctx.save_for_backward(idx, vi, u, fx, stats, pe, a1, h1, a2, score, w, *keep)
         ctx.training = bool(training)
+        ctx.fused_backward = bool(fused_backward)
         return agg
 
     @staticmethod
     def backward(ctx, dagg):
         idx, vi, u, fx, stats, pe, a1, h1, a2, score, w, *keep = ctx.saved_tensors
-        if pe is None:
-            raise RuntimeError('pcf_chain: backward needs the training-mode forward (activations were not kept)')
+        if not ctx.training:
+            raise RuntimeError('pcf_chain: backward needs the training-mode forward (batch statistics)')
         Ws, bs, gammas, betas = keep[0::4], keep[1::4], keep[2::4], keep[3::4]
         tr = ctx.training
-        K = idx.shape[2]
+        B, M, K, cv = vi.shape
         st = lambda l: (stats[l], stats[6 + l])
+        if ctx.fused_backward:
+            dev = dagg.device
+            with torch.cuda.device(dev):
+                dfx, dscore, dw = pcf_cuda.pcf_backward(dagg.contiguous(), fx, idx, score, w)
+                du = torch.empty_like(u)
+                grads = [torch.empty_like(t) for t in keep]
+                nbytes = _chain_bwd_ws()
+                ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                _call(_chain_bwd, _ptr(vi), _ptr(idx), _ptr(u), _ptr(dscore), _ptr(dw), B * M * K, M * K, u.shape[1], K, cv,
+                      Ws[0].shape[0], Ws[2].shape[0], Ws[5].shape[0], _ptr_array(Ws), _ptr_array(bs), _ptr_array(gammas),
+                      _ptr_array(betas), stats.data_ptr(), _ptr(du), _ptr_array(grads[0::4]), _ptr_array(grads[1::4]),
+                      _ptr_array(grads[2::4]), _ptr_array(grads[3::4]), ws.data_ptr(), nbytes, _stream(dev))
+            return (None, None, None, None, None, du, dfx, *grads)
         with torch.cuda.device(dagg.device):
             dfx, dscore, dw = pcf_cuda.pcf_backward(dagg.contiguous(), fx, idx, score, w)
             L = {}
@@ -490,7 +513,7 @@ class _PCFChain(torch.autograd.Function):
         grads = []
         for l in range(6):
             grads.extend(L[l])
-        return (None, None, None, None, du, dfx, *grads)
+        return (None, None, None, None, None, du, dfx, *grads)
 
 
 def pcf_chain_supported(cv, g, heads, cm, K, hidden_ok, n_edges):
@@ -499,9 +522,10 @@ def pcf_chain_supported(cv, g, heads, cm, K, hidden_ok, n_edges):
         and 1 <= K <= 16 and (K & (K - 1)) == 0 and n_edges % 16 == 0
 
 
-def pcf_chain(vi, idx, u, fx, layers, training):
+def pcf_chain(vi, idx, u, fx, layers, training, fused_backward=True):
     """layers: six (nn.Linear, nn.BatchNorm1d) pairs in the order mlp_conv, g1, g2, w1, w2, w3; the g1 weight is
-    split here (its gathered half already went into `u`)."""
+    split here (its gathered half already went into `u`).  fused_backward: adjoint through the four-pass
+    recompute kernel (csrc/edge_chain_bwd.hip); False keeps the activations and goes layer by layer."""
     _floats(vi=vi, u=u, fx=fx)
     _check_input(idx, 'nei_inds', torch.int64)
     G = layers[0][0].out_features
@@ -509,4 +533,4 @@ def pcf_chain(vi, idx, u, fx, layers, training):
     for l, (lin, bn) in enumerate(layers):
         W = lin.weight[:, lin.weight.shape[1] - G:] if l == 1 else lin.weight
         params += [W, lin.bias, bn.weight, bn.bias]
-    return _PCFChain.apply(idx, [bn for _, bn in layers], training, vi, u, fx, *params)
+    return _PCFChain.apply(idx, [bn for _, bn in layers], training, fused_backward, vi, u, fx, *params)

@@ -346,7 +346,8 @@ class PCFLayer(nn.Module):
             G = guidance_x.shape[-1]
             u = pcf_fused.linear_bn_act(guidance_x, g1.weight[:, :G], g1.weight.new_zeros(g1.out_features), None,
                                         pcf_fused.ACT_NONE, self.training)
-            agg = pcf_fused.pcf_chain(wn_in.contiguous(), nei_inds, u, feats_x.contiguous(), chain, self.training)
+            agg = pcf_fused.pcf_chain(wn_in.contiguous(), nei_inds, u, feats_x.contiguous(), chain, self.training,
+                                      fused_backward=not getattr(self.cfg, 'EDGE_CHAIN_LAYERWISE_BACKWARD', False))
         else:
             feat_pe = _linear_act(self.mlp_conv, wn_in, pcf_fused.ACT_RELU)
             if not strided and pcf_fused.split_guidance_supported(nei_inds.shape[2], 8) \

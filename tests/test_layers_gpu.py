@@ -84,13 +84,56 @@ def _run(layer, g, device, feat_keys, order, opt=False):
 PCF_ORDER = ['dense_xyz', 'dense_feats', 'nei_inds', 'dense_xyz_norm', 'sparse_xyz', 'sparse_xyz_norm']
 
 
+# edge graph: fused forward + fused four-pass backward (default) / fused forward + layer-at-a-time backward /
+# every layer through its own kernels
+CHAIN_MODES = {'fused': {}, 'layerwise_bwd': dict(EDGE_CHAIN_LAYERWISE_BACKWARD=True), 'off': dict(NO_EDGE_CHAIN=True)}
+
+
+@pytest.mark.parametrize('mode', list(CHAIN_MODES))
 @pytest.mark.parametrize('name,ci,co,cm,heads', [('pcf_self_64', 64, 64, 16, 8), ('pcf_self_32_64', 32, 64, 16, 8),
                                                  ('pcf_strided', 32, 64, 4, 4)])
-def test_pcf_layer_matches_reference(device, name, ci, co, cm, heads):
+def test_pcf_layer_matches_reference(device, name, ci, co, cm, heads, mode):
     import pcf_layers
     g = load_golden(name)
-    layer = pcf_layers.PCFLayer(ci, co, cfg(), weightnet=[12, cm], num_heads=heads, guidance_feat_len=32)
+    layer = pcf_layers.PCFLayer(ci, co, cfg(**CHAIN_MODES[mode]), weightnet=[12, cm], num_heads=heads,
+                                guidance_feat_len=32)
     _run(layer, g, device, ['dense_feats'], PCF_ORDER)
+
+
+@pytest.mark.parametrize('B,N,K,cm,heads,gfl', [(2, 3000, 16, 16, 8, 32), (1, 4096, 8, 8, 4, 16), (3, 1000, 4, 16, 8, 20)])
+def test_fused_edge_chain_backward_against_layerwise(device, B, N, K, cm, heads, gfl):
+    """The four-pass recompute backward (edge_chain_bwd.hip) against the layer-at-a-time kernels on a random
+    layer: same forward, gradients of the features, of the per-point guidance term and of all 24 parameters."""
+    import pcf_layers
+    torch.manual_seed(5)
+    xyz = torch.rand(B, N, 3, device=device)
+    nrm = torch.nn.functional.normalize(torch.randn(B, N, 3, device=device), dim=-1)
+    d = torch.cdist(xyz, xyz)
+    nei = d.topk(K, dim=-1, largest=False).indices.contiguous()
+    feats = torch.randn(B, N, 32, device=device)
+    up = torch.randn(B, N, 64, device=device)
+    grads = {}
+    for mode in ('fused', 'layerwise_bwd'):
+        torch.manual_seed(11)
+        layer = pcf_layers.PCFLayer(32, 64, cfg(**CHAIN_MODES[mode]), weightnet=[12, cm], num_heads=heads,
+                                    guidance_feat_len=gfl).to(device).train()
+        with torch.no_grad():       # non-trivial BatchNorm affine parameters
+            for m in layer.modules():
+                if isinstance(m, torch.nn.BatchNorm1d) or isinstance(m, torch.nn.BatchNorm2d):
+                    m.weight.uniform_(0.5, 1.5)
+                    m.bias.uniform_(-0.3, 0.3)
+        assert layer._chain_layers(torch.empty(B, N, K, 12), nei) is not None
+        x = feats.clone().requires_grad_(True)
+        out, _ = layer(xyz, x, nei, nrm)
+        out.backward(up)
+        grads[mode] = dict(out=out.detach(), x=x.grad, **{n: p.grad for n, p in layer.named_parameters()})
+    # Some gradients are analytically zero (a bias in front of a batch-stat BN; any constant shift of the guidance
+    # features, which q - key cancels) and hold only rounding noise: absolute slack tied to the largest gradient.
+    top = max(float(t.abs().max()) for k, t in grads['layerwise_bwd'].items() if k not in ('out', 'x'))
+    for k, v in grads['fused'].items():
+        ref = grads['layerwise_bwd'][k]
+        scale = float(ref.abs().max()) + 1e-6
+        torch.testing.assert_close(v, ref, rtol=1e-3, atol=2e-4 * scale + 2e-5 * top, msg=lambda m, n=k: f'{n}: {m}')
 
 
 @pytest.mark.parametrize('opt', [False, True])
