@@ -47,6 +47,26 @@ __device__ __forceinline__ float wfrag(const float* W, int Cout, int Cin, int o,
     return (W && o < Cout && c < Cin) ? W[o * Cin + c] : 0.f;
 }
 
+// Batch of edge e0 + p (e0 = 16 * tile, wave-uniform) for a non-decreasing sequence of tiles, without the
+// software 64-bit division `e / rows_per_batch` costs per call (~100 VALU instructions).  rows_per_batch >= 16,
+// so at most one batch boundary falls inside a tile.
+struct BatchWalk {
+    long long rpb, next_start;
+    int b;
+    __device__ __forceinline__ void init(long long rows_per_batch) { rpb = rows_per_batch; next_start = rows_per_batch; b = 0; }
+    __device__ __forceinline__ int batch_of(long long e0, int p) {
+        if (e0 >= next_start) {
+            if (e0 - next_start < 4 * rpb) {
+                do { ++b; next_start += rpb; } while (e0 >= next_start);
+            } else {
+                b = (int)(e0 / rpb);
+                next_start = (long long)(b + 1) * rpb;
+            }
+        }
+        return b + (e0 + p >= next_start ? 1 : 0);
+    }
+};
+
 #define PCF_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_16x16x4f32((A), (B), (C), 0, 0, 0)
 
 // up to 4 workgroups per CU; every wave walks tiles with a grid stride

@@ -99,10 +99,14 @@ __global__ __launch_bounds__(BLOCK) void pcf_chain_kernel(const ChainArgs a) {
         }
         return xv;
     };
-    auto load_j = [&](long long tt) -> long long {
-        if (LEVEL < 2 || g >= 2 || tt >= ntiles) return -1;
+    BatchWalk walk;
+    walk.init(a.rows_per_batch);
+    auto load_j = [&](long long tt) -> long long {       // called with increasing tt only
+        if (LEVEL < 2 || tt >= ntiles) return -1;
+        const int batch = walk.batch_of(tt * 16, p);
+        if (g >= 2) return -1;
         const int64_t j = a.idx[tt * 16 + p];
-        return (j >= 0 && j < a.N) ? (long long)((tt * 16 + p) / a.rows_per_batch) * a.N + j : -1;
+        return (j >= 0 && j < a.N) ? (long long)batch * a.N + j : -1;
     };
     auto load_u = [&](long long row) -> f32x4 {
         f32x4 uv = zero4;
@@ -307,8 +311,8 @@ int pcf_hip_pcf_chain_forward(const float* vi, const int64_t* idx, const float* 
     PCF_REQUIRE(E >= 0 && rows_per_batch > 0 && N >= 0, "pcf_chain: bad sizes");
     if (cv < 1 || cv > CV || g < 1 || g > CG || heads < 1 || heads > CHD || cm < 1 || cm > CMX)
         return fail(PCF_E_UNSUPPORTED, "pcf_chain: widths outside the fused kernel (cv=%d<=12, g=%d<=32, heads=%d<=8, cm=%d<=16)", cv, g, heads, cm);
-    if (K < 1 || K > 16 || (K & (K - 1)) != 0 || E % 16 != 0 || E % rows_per_batch != 0)
-        return fail(PCF_E_UNSUPPORTED, "pcf_chain: K must be a power of two <= 16 and the edge count a multiple of 16 (K=%d)", K);
+    if (K < 1 || K > 16 || (K & (K - 1)) != 0 || E % 16 != 0 || E % rows_per_batch != 0 || rows_per_batch < 16)
+        return fail(PCF_E_UNSUPPORTED, "pcf_chain: K must be a power of two <= 16, the edge count a multiple of 16 and >= 16 edges per batch (K=%d)", K);
     if (E == 0) return ok();
     PCF_REQUIRE(vi && idx && u && W && b && gamma && beta && stats && score && w, "pcf_chain: null pointer");
     PCF_REQUIRE(aligned16(score) && aligned16(w) && aligned16(pe) && aligned16(a1) && aligned16(h1) && aligned16(a2) &&

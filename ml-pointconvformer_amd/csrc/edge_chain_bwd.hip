@@ -24,13 +24,18 @@
 
 #include "edge_chain.h"
 
+// fused multiply-adds in the per-element BatchNorm algebra (the library default is contraction off)
+#pragma clang fp contract(fast)
+
 namespace pcf {
 
-constexpr int TT = 17;              // row stride of the 16x16 transposition tiles
+constexpr int TT = 20;              // row stride of the 16x16 transposition tiles ([edge][channel], 16-byte aligned rows)
 constexpr int NFRAG = 13;
 constexpr int NSLOT = 7;            // output-tile slots: pe lo, pe hi, w1, g1, w2, g2, w3
 constexpr int NDW = 8;              // 16x16 weight-gradient tiles: pe lo, pe hi, w1, g1 (in lo), g1 (in hi), w2, g2, w3
-enum { K_RSTD = 0, K_X0 = 1, K_GAMMA = 2, K_BETA = 3, K_GM = 4, K_GXM = 5, NCONST = 6 };
+// per-channel constants of a slot: pre-activation = acc * SC + SH (acc = raw accumulator, bias folded in),
+// dz = g * SC + acc * D1 + D0  (the BatchNorm backward written in terms of the raw accumulator, see stage_consts)
+enum { K_SC = 0, K_SH = 1, K_D0 = 2, K_D1 = 3, NCONST = 4 };
 enum { S_PE0 = 0, S_PE1 = 1, S_W1 = 2, S_G1 = 3, S_W2 = 4, S_G2 = 5, S_W3 = 6 };
 
 struct ChainBwdArgs {
@@ -43,7 +48,11 @@ struct ChainBwdArgs {
     float* part;                // pass partials
 };
 
-// constants of slot s, channel c of the tile
+// constants of slot s, channel c of the tile.  With rs = rstd, x0 = (b - mean) * rs, xhat = acc * rs + x0:
+//   pre = xhat * gamma + beta = acc * (rs * gamma) + (x0 * gamma + beta)
+//   dz  = gamma * rs * (g - mean(g) - xhat * mean(g xhat)) = g * SC + acc * D1 + D0
+//         with D1 = -SC * mean(g xhat) * rs,  D0 = -SC * (mean(g) + mean(g xhat) * x0)
+// so neither xhat nor the BatchNorm statistics are touched per element.
 __device__ __forceinline__ void stage_consts(const ChainBwdArgs& a, float (*cf)[NCONST][16], int level) {
     const int layer_of[NSLOT] = {L_PE, L_PE, L_W1, L_G1, L_W2, L_G2, L_W3};
     const int tile_of[NSLOT] = {0, 1, 0, 0, 0, 0, 0};
@@ -52,13 +61,16 @@ __device__ __forceinline__ void stage_consts(const ChainBwdArgs& a, float (*cf)[
     for (int t = threadIdx.x; t < NSLOT * 16; t += BLOCK) {
         const int s = t >> 4, c = t & 15;
         const int layer = layer_of[s], o = 16 * tile_of[s] + c;
-        float v[NCONST] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float v[NCONST] = {0.f, 0.f, 0.f, 0.f};
         if (o < cout_of[s]) {
-            v[K_RSTD] = a.f.rstd[layer][o];
-            v[K_X0] = (a.f.b[layer][o] - a.f.mean[layer][o]) * v[K_RSTD];
-            v[K_GAMMA] = a.f.gamma[layer][o];
-            v[K_BETA] = a.f.beta[layer][o];
-            if (level >= need_level[s]) { v[K_GM] = a.gmean[layer][o]; v[K_GXM] = a.gxmean[layer][o]; }
+            const float rs = a.f.rstd[layer][o], x0 = (a.f.b[layer][o] - a.f.mean[layer][o]) * rs;
+            v[K_SC] = rs * a.f.gamma[layer][o];
+            v[K_SH] = x0 * a.f.gamma[layer][o] + a.f.beta[layer][o];
+            if (level >= need_level[s]) {
+                const float gm = a.gmean[layer][o], gxm = a.gxmean[layer][o];
+                v[K_D1] = -v[K_SC] * gxm * rs;
+                v[K_D0] = -v[K_SC] * (gm + gxm * x0);
+            }
         }
 #pragma unroll
         for (int k = 0; k < NCONST; ++k) cf[s][k][c] = v[k];
@@ -106,14 +118,10 @@ __device__ __forceinline__ f32x4 mm(const float4* wl, int frag, int lane, f32x4 
     return acc;
 }
 
-// xhat of a raw accumulator tile (bias folded into x0)
-__device__ __forceinline__ f32x4 xhat_of(f32x4 acc, const float (*k)[16], int g) {
-    const f32x4 rs = to_v4(ld4(&k[K_RSTD][4 * g])), x0 = to_v4(ld4(&k[K_X0][4 * g]));
-    return acc * rs + x0;
-}
-__device__ __forceinline__ f32x4 pre_of(f32x4 xh, const float (*k)[16], int g) {
-    const f32x4 ga = to_v4(ld4(&k[K_GAMMA][4 * g])), be = to_v4(ld4(&k[K_BETA][4 * g]));
-    return xh * ga + be;
+// pre-activation (BatchNorm applied) of a raw accumulator tile
+__device__ __forceinline__ f32x4 pre_of(f32x4 acc, const float (*k)[16], int g) {
+    const f32x4 sc = to_v4(ld4(&k[K_SC][4 * g])), sh = to_v4(ld4(&k[K_SH][4 * g]));
+    return acc * sc + sh;
 }
 __device__ __forceinline__ f32x4 relu4(f32x4 v) {
     return f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
@@ -121,53 +129,33 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) {
 __device__ __forceinline__ f32x4 mask_pos(f32x4 d, f32x4 pre) {
     return f32x4{pre[0] > 0.f ? d[0] : 0.f, pre[1] > 0.f ? d[1] : 0.f, pre[2] > 0.f ? d[2] : 0.f, pre[3] > 0.f ? d[3] : 0.f};
 }
-// dz = gamma * rstd * (g - mean g - xhat * mean(g xhat)); zero outside the layer's channels (constants are 0 there)
-__device__ __forceinline__ f32x4 bn_dz(f32x4 gr, f32x4 xh, const float (*k)[16], int g) {
-    const f32x4 rs = to_v4(ld4(&k[K_RSTD][4 * g])), ga = to_v4(ld4(&k[K_GAMMA][4 * g]));
-    const f32x4 gm = to_v4(ld4(&k[K_GM][4 * g])), gxm = to_v4(ld4(&k[K_GXM][4 * g]));
-    return ga * rs * (gr - gm - xh * gxm);
+// dz of a BatchNorm layer from g = dy * act' and the raw accumulator; zero outside the layer's channels
+// (all constants are 0 there)
+__device__ __forceinline__ f32x4 bn_dz(f32x4 gr, f32x4 acc, const float (*k)[16], int g) {
+    const f32x4 sc = to_v4(ld4(&k[K_SC][4 * g])), d0 = to_v4(ld4(&k[K_D0][4 * g])), d1 = to_v4(ld4(&k[K_D1][4 * g]));
+    return gr * sc + (acc * d1 + d0);
 }
 
-// one 16x16 tile [channel 4g+r][edge p] -> LDS [channel][edge]
+// one 16x16 tile (lane (p, g): channels 4g..4g+3 of edge p) -> LDS [edge][channel], one 16-byte store per lane
 __device__ __forceinline__ void put_tile(float* buf, f32x4 v, int p, int g) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) buf[(4 * g + r) * TT + p] = v[r];
+    st4(buf + p * TT + 4 * g, make_float4(v[0], v[1], v[2], v[3]));
 }
-// dW tile += sum over the 16 edges of dz[o][e] * in[c][e]
+// dW tile += sum over the 16 edges of dz[o][e] * in[c][e]: operand lane (i = l & 15, k = l >> 4) of step s holds
+// element [channel i][edge 4s + k]
 __device__ __forceinline__ f32x4 outer(const float* dzbuf, const float* inbuf, int p, int g, f32x4 acc) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) acc = PCF_MFMA(dzbuf[p * TT + 4 * s + g], inbuf[p * TT + 4 * s + g], acc);
+    for (int s = 0; s < 4; ++s) acc = PCF_MFMA(dzbuf[(4 * s + g) * TT + p], inbuf[(4 * s + g) * TT + p], acc);
     return acc;
 }
 
-template <int LEVEL>
-__global__ __launch_bounds__(BLOCK) void pcf_chain_bwd_kernel(const ChainBwdArgs a) {
-    __shared__ __align__(16) float cf[NSLOT][NCONST][16];
-    __shared__ float4 wl[NFRAG * WAVE];
-    __shared__ float red[LEVEL == 4 ? NDW * 256 : NWAVE * 96];
-    __shared__ float tbuf[LEVEL == 4 ? NWAVE * 5 * 16 * TT : 1];
-    __shared__ int gi[NWAVE][16];
-    const ChainArgs& f = a.f;
-    stage_consts(a, cf, LEVEL);
-    stage_weights(a, wl);
-    if (LEVEL == 4)
-        for (int t = threadIdx.x; t < NDW * 256; t += BLOCK) red[t] = 0.f;
-    __syncthreads();
-    const int lane = lane_id(), wave = wave_id();
-    const int p = lane & 15, g = lane >> 4;
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 s1[3] = {zero4, zero4, zero4}, s2[3] = {zero4, zero4, zero4};
-    f32x4 accw[NDW];
-#pragma unroll
-    for (int i = 0; i < NDW; ++i) accw[i] = zero4;
-    const int lead = (lane & ~15) | (p & ~(f.K - 1));
-    const bool first = (p & (f.K - 1)) == 0;
-    const long long ntiles = f.E / 16;
-    const long long tstride = (long long)gridDim.x * NWAVE;
-    float* tb = LEVEL == 4 ? tbuf + wave * 5 * 16 * TT : tbuf;
-
-    auto load_x = [&](long long tt) -> f32x4 {
-        f32x4 xv = zero4;
+// Tile loaders shared by the two branches.
+struct TileIO {
+    const ChainBwdArgs& a;
+    int p, g;
+    long long ntiles;
+    __device__ __forceinline__ f32x4 load_x(long long tt) const {
+        const ChainArgs& f = a.f;
+        f32x4 xv = {0.f, 0.f, 0.f, 0.f};
         if (tt < ntiles && 4 * g < f.cv) {
             const float* q = f.vi + (size_t)(tt * 16 + p) * f.cv + 4 * g;
             if (f.vec_vi) xv = to_v4(ld4(q));
@@ -177,18 +165,10 @@ __global__ __launch_bounds__(BLOCK) void pcf_chain_bwd_kernel(const ChainBwdArgs
             }
         }
         return xv;
-    };
-    auto load_j = [&](long long tt) -> long long {
-        if (tt >= ntiles) return -1;
-        const int64_t j = f.idx[tt * 16 + p];
-        return (j >= 0 && j < f.N) ? (long long)((tt * 16 + p) / f.rows_per_batch) * f.N + j : -1;
-    };
-    auto load_u = [&](long long row) -> f32x4 {
-        return (row >= 0 && g < 2) ? to_v4(ld4(f.u + (size_t)row * CH + 4 * g)) : zero4;
-    };
-    auto load_grad = [&](const float* base, long long tt, int C) -> f32x4 {
-        f32x4 v = zero4;
-        if (4 * g < C) {
+    }
+    __device__ __forceinline__ f32x4 load_grad(const float* base, long long tt, int C) const {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (tt < ntiles && 4 * g < C) {
             const float* q = base + (size_t)(tt * 16 + p) * C + 4 * g;
             if ((C & 3) == 0) v = to_v4(ld4(q));
             else {
@@ -197,150 +177,272 @@ __global__ __launch_bounds__(BLOCK) void pcf_chain_bwd_kernel(const ChainBwdArgs
             }
         }
         return v;
-    };
+    }
+};
 
-    long long t = (long long)blockIdx.x * NWAVE + wave;
-    f32x4 x = load_x(t), x_next = load_x(t + tstride);
+// The two branches of the edge graph share nothing but the VI row, so every pass runs them in DIFFERENT
+// workgroups of one launch (5 of every 8 workgroups take the guidance branch, which has 5/8 of the matrix work):
+// each wave then holds the live state of one branch only -- about half the registers, twice the resident waves.
+//
+// Guidance branch: VI -> pe (<= 32) -> g1 (8, + gathered u, - key) -> g2 (heads, sigmoid).
+//   red (LEVEL < 4): groups {L1: g2 | L2: g1 | L3: pe lo, pe hi};   LEVEL 4: dW tiles 0, 1, 3, 4, 6 and du.
+template <int LEVEL>
+__device__ __forceinline__ void guidance_branch(const ChainBwdArgs& a, const float (*cf)[NCONST][16], const float4* wl,
+                                                float* red, float* tb, int* gi, long long t0, long long tstride) {
+    const ChainArgs& f = a.f;
+    const int lane = lane_id(), wave = wave_id(), p = lane & 15, g = lane >> 4;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const long long ntiles = f.E / 16;
+    const TileIO io{a, p, g, ntiles};
+    f32x4 s1[2] = {zero4, zero4}, s2[2] = {zero4, zero4};
+    f32x4 accw[5] = {zero4, zero4, zero4, zero4, zero4};          // pe lo, pe hi, g1 (in lo), g1 (in hi), g2
+    const int lead = (lane & ~15) | (p & ~(f.K - 1));
+    const bool first = (p & (f.K - 1)) == 0;
+    BatchWalk walk;
+    walk.init(f.rows_per_batch);
+    auto load_j = [&](long long tt) -> long long {               // called with increasing tt only
+        if (tt >= ntiles) return -1;
+        const int batch = walk.batch_of(tt * 16, p);
+        const int64_t j = f.idx[tt * 16 + p];
+        return (j >= 0 && j < f.N) ? (long long)batch * f.N + j : -1;
+    };
+    auto load_u = [&](long long row) -> f32x4 {
+        return (row >= 0 && g < 2) ? to_v4(ld4(f.u + (size_t)row * CH + 4 * g)) : zero4;
+    };
+    long long t = t0;
+    f32x4 x = io.load_x(t);
     long long j_cur = load_j(t);
     f32x4 ucur = load_u(j_cur);
     long long j_next = load_j(t + tstride);
     for (; t < ntiles; t += tstride) {
         asm volatile("" ::: "memory");          // LDS-resident weights / constants are re-read per tile, not hoisted into VGPRs
-        // prefetch: gathered u row of tile t+1, index and input of tile t+2, upstream gradients of this tile
-        const f32x4 u_next = load_u(j_next);
+        const f32x4 u_next = load_u(j_next);                      // gather of tile t+1, index of tile t+2, input of tile t+1
         const long long j_nn = load_j(t + 2 * tstride);
-        const f32x4 x_nn = load_x(t + 2 * tstride);
-        const f32x4 dsc = load_grad(a.dscore, t, f.heads);
-        const f32x4 dwv = load_grad(a.dw, t, f.cm);
+        const f32x4 x_next = io.load_x(t + tstride);
+        const f32x4 dsc = io.load_grad(a.dscore, t, f.heads);
 
-        // ---- forward, keeping xhat of every layer ----
-        const f32x4 xh_pe0 = xhat_of(mm(wl, 0, lane, x, zero4), cf[S_PE0], g);
-        const f32x4 xh_pe1 = xhat_of(mm(wl, 1, lane, x, zero4), cf[S_PE1], g);
-        const f32x4 xh_a1 = xhat_of(mm(wl, 2, lane, x, zero4), cf[S_W1], g);
-        const f32x4 y_pe0 = relu4(pre_of(xh_pe0, cf[S_PE0], g));
-        const f32x4 y_pe1 = relu4(pre_of(xh_pe1, cf[S_PE1], g));
-        const f32x4 y_a1 = relu4(pre_of(xh_a1, cf[S_W1], g));
+        // ---- forward, keeping the raw accumulator (ac_*) of every layer ----
+        const f32x4 ac_pe0 = mm(wl, 0, lane, x, zero4);
+        const f32x4 ac_pe1 = mm(wl, 1, lane, x, zero4);
+        const f32x4 y_pe0 = relu4(pre_of(ac_pe0, cf[S_PE0], g));
+        const f32x4 y_pe1 = relu4(pre_of(ac_pe1, cf[S_PE1], g));
         f32x4 h1 = mm(wl, 3, lane, y_pe0, zero4);
         const f32x4 h1b = mm(wl, 4, lane, y_pe1, zero4);
-        const f32x4 xh_a2 = xhat_of(mm(wl, 5, lane, y_a1, zero4), cf[S_W2], g);
         h1 = h1 + h1b + ucur;
 #pragma unroll
         for (int r = 0; r < 4; ++r) h1[r] -= __shfl(h1[r], lead, WAVE);
-        const f32x4 xh_h1 = xhat_of(h1, cf[S_G1], g);
-        const f32x4 y_h1 = relu4(pre_of(xh_h1, cf[S_G1], g));
-        const f32x4 y_a2 = relu4(pre_of(xh_a2, cf[S_W2], g));
-        const f32x4 xh_sc = xhat_of(mm(wl, 6, lane, y_h1, zero4), cf[S_G2], g);
-        const f32x4 xh_w = xhat_of(mm(wl, 7, lane, y_a2, zero4), cf[S_W3], g);
-        const f32x4 pre_sc = pre_of(xh_sc, cf[S_G2], g);
-        const f32x4 pre_w = pre_of(xh_w, cf[S_W3], g);
+        const f32x4 ac_h1 = h1;
+        const f32x4 y_h1 = relu4(pre_of(ac_h1, cf[S_G1], g));
+        const f32x4 ac_sc = mm(wl, 6, lane, y_h1, zero4);
+        const f32x4 pre_sc = pre_of(ac_sc, cf[S_G2], g);
 
-        // ---- top of the backward: g of g2 (sigmoid) and w3 (ReLU) ----
-        f32x4 g_sc, g_w = mask_pos(dwv, pre_w);
+        // ---- backward ----
+        f32x4 g_sc;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float sg = 1.f / (1.f + __expf(-pre_sc[r]));
             g_sc[r] = dsc[r] * sg * (1.f - sg);
         }
         if (LEVEL == 1) {
-            s1[0] += g_sc; s2[0] += g_sc * xh_sc;
-            s1[1] += g_w;  s2[1] += g_w * xh_w;
-            x = x_next; x_next = x_nn; ucur = u_next; j_cur = j_next; j_next = j_nn;
-            continue;
-        }
-        const f32x4 dz_sc = bn_dz(g_sc, xh_sc, cf[S_G2], g);
-        const f32x4 dz_w = bn_dz(g_w, xh_w, cf[S_W3], g);
-        if (LEVEL == 4) {
-            put_tile(tb + 0 * 16 * TT, dz_sc, p, g);
-            put_tile(tb + 1 * 16 * TT, y_h1, p, g);
-            put_tile(tb + 2 * 16 * TT, dz_w, p, g);
-            put_tile(tb + 3 * 16 * TT, y_a2, p, g);
-            accw[6] = outer(tb + 0 * 16 * TT, tb + 1 * 16 * TT, p, g, accw[6]);
-            accw[7] = outer(tb + 2 * 16 * TT, tb + 3 * 16 * TT, p, g, accw[7]);
-        }
-        const f32x4 g_h1 = mask_pos(mm(wl, 8, lane, dz_sc, zero4), y_h1);
-        const f32x4 g_a2 = mask_pos(mm(wl, 9, lane, dz_w, zero4), y_a2);
-        if (LEVEL == 2) {
-            s1[0] += g_h1; s2[0] += g_h1 * xh_h1;
-            s1[1] += g_a2; s2[1] += g_a2 * xh_a2;
-            x = x_next; x_next = x_nn; ucur = u_next; j_cur = j_next; j_next = j_nn;
-            continue;
-        }
-        f32x4 dq = bn_dz(g_h1, xh_h1, cf[S_G1], g);
-        const f32x4 dz_a2 = bn_dz(g_a2, xh_a2, cf[S_W2], g);
-        // z[k] = q[k] - q[key] + b  =>  dq[k] = dz[k] - [k is the key] * (sum over the neighbourhood)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float tot = dq[r];
-            for (int off = 1; off < f.K; off <<= 1) tot += __shfl_xor(tot, off, WAVE);
-            if (first) dq[r] -= tot;
-        }
-        if (LEVEL == 4) {
-            put_tile(tb + 0 * 16 * TT, dq, p, g);
-            put_tile(tb + 1 * 16 * TT, y_pe0, p, g);
-            put_tile(tb + 2 * 16 * TT, y_pe1, p, g);
-            put_tile(tb + 3 * 16 * TT, dz_a2, p, g);
-            put_tile(tb + 4 * 16 * TT, y_a1, p, g);
-            // gradient of the gathered term: consecutive lanes cover the 8 consecutive channels of one row of du
-            if (g == 0) gi[wave][p] = (int)j_cur;
-            for (int e = lane; e < 16 * CH; e += WAVE) {
-                const int r = e / CH, o = e - r * CH;
-                const int tgt = gi[wave][r];
-                if (tgt >= 0) atomicAdd(a.du + (size_t)tgt * CH + o, tb[o * TT + r]);
+            s1[0] += g_sc; s2[0] += g_sc * ac_sc;
+        } else {
+            const f32x4 dz_sc = bn_dz(g_sc, ac_sc, cf[S_G2], g);
+            if (LEVEL == 4) {
+                put_tile(tb + 0 * 16 * TT, dz_sc, p, g);
+                put_tile(tb + 1 * 16 * TT, y_h1, p, g);
+                accw[4] = outer(tb + 0 * 16 * TT, tb + 1 * 16 * TT, p, g, accw[4]);
             }
-            accw[3] = outer(tb + 0 * 16 * TT, tb + 1 * 16 * TT, p, g, accw[3]);
-            accw[4] = outer(tb + 0 * 16 * TT, tb + 2 * 16 * TT, p, g, accw[4]);
-            accw[5] = outer(tb + 3 * 16 * TT, tb + 4 * 16 * TT, p, g, accw[5]);
+            const f32x4 g_h1 = mask_pos(mm(wl, 8, lane, dz_sc, zero4), y_h1);
+            if (LEVEL == 2) {
+                s1[0] += g_h1; s2[0] += g_h1 * ac_h1;
+            } else {
+                f32x4 dq = bn_dz(g_h1, ac_h1, cf[S_G1], g);
+                // z[k] = q[k] - q[key] + b  =>  dq[k] = dz[k] - [k is the key] * (sum over the neighbourhood)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float tot = dq[r];
+                    for (int off = 1; off < f.K; off <<= 1) tot += __shfl_xor(tot, off, WAVE);
+                    if (first) dq[r] -= tot;
+                }
+                if (LEVEL == 4) {
+                    put_tile(tb + 0 * 16 * TT, dq, p, g);
+                    put_tile(tb + 1 * 16 * TT, y_pe0, p, g);
+                    put_tile(tb + 2 * 16 * TT, y_pe1, p, g);
+                    // gradient of the gathered term: consecutive lanes cover the 8 consecutive channels of one row of du
+                    if (g == 0) gi[p] = (int)j_cur;
+                    for (int e = lane; e < 16 * CH; e += WAVE) {
+                        const int r = e / CH, o = e - r * CH;
+                        const int tgt = gi[r];
+                        if (tgt >= 0) atomicAdd(a.du + (size_t)tgt * CH + o, tb[r * TT + o]);
+                    }
+                    accw[2] = outer(tb + 0 * 16 * TT, tb + 1 * 16 * TT, p, g, accw[2]);
+                    accw[3] = outer(tb + 0 * 16 * TT, tb + 2 * 16 * TT, p, g, accw[3]);
+                }
+                const f32x4 g_pe0 = mask_pos(mm(wl, 10, lane, dq, zero4), y_pe0);
+                const f32x4 g_pe1 = mask_pos(mm(wl, 11, lane, dq, zero4), y_pe1);
+                if (LEVEL == 3) {
+                    s1[0] += g_pe0; s2[0] += g_pe0 * ac_pe0;
+                    s1[1] += g_pe1; s2[1] += g_pe1 * ac_pe1;
+                } else {
+                    put_tile(tb + 0 * 16 * TT, bn_dz(g_pe0, ac_pe0, cf[S_PE0], g), p, g);
+                    put_tile(tb + 1 * 16 * TT, bn_dz(g_pe1, ac_pe1, cf[S_PE1], g), p, g);
+                    put_tile(tb + 2 * 16 * TT, x, p, g);
+                    accw[0] = outer(tb + 0 * 16 * TT, tb + 2 * 16 * TT, p, g, accw[0]);
+                    accw[1] = outer(tb + 1 * 16 * TT, tb + 2 * 16 * TT, p, g, accw[1]);
+                }
+            }
         }
-        const f32x4 g_pe0 = mask_pos(mm(wl, 10, lane, dq, zero4), y_pe0);
-        const f32x4 g_pe1 = mask_pos(mm(wl, 11, lane, dq, zero4), y_pe1);
-        const f32x4 g_a1 = mask_pos(mm(wl, 12, lane, dz_a2, zero4), y_a1);
-        if (LEVEL == 3) {
-            s1[0] += g_pe0; s2[0] += g_pe0 * xh_pe0;
-            s1[1] += g_pe1; s2[1] += g_pe1 * xh_pe1;
-            s1[2] += g_a1;  s2[2] += g_a1 * xh_a1;
-            x = x_next; x_next = x_nn; ucur = u_next; j_cur = j_next; j_next = j_nn;
-            continue;
-        }
-        if (LEVEL == 4) {
-            put_tile(tb + 0 * 16 * TT, bn_dz(g_pe0, xh_pe0, cf[S_PE0], g), p, g);
-            put_tile(tb + 1 * 16 * TT, bn_dz(g_pe1, xh_pe1, cf[S_PE1], g), p, g);
-            put_tile(tb + 2 * 16 * TT, bn_dz(g_a1, xh_a1, cf[S_W1], g), p, g);
-            put_tile(tb + 3 * 16 * TT, x, p, g);
-            accw[0] = outer(tb + 0 * 16 * TT, tb + 3 * 16 * TT, p, g, accw[0]);
-            accw[1] = outer(tb + 1 * 16 * TT, tb + 3 * 16 * TT, p, g, accw[1]);
-            accw[2] = outer(tb + 2 * 16 * TT, tb + 3 * 16 * TT, p, g, accw[2]);
-        }
-        x = x_next; x_next = x_nn; ucur = u_next; j_cur = j_next; j_next = j_nn;
+        x = x_next; ucur = u_next; j_cur = j_next; j_next = j_nn;
     }
-
     if (LEVEL == 4) {
-        // combine the four waves in wave order (deterministic): red[tile][o][c]
-        for (int wv = 0; wv < NWAVE; ++wv) {
+        const int tiles[5] = {0, 1, 3, 4, 6};
+        for (int wv = 0; wv < NWAVE; ++wv) {        // wave order: deterministic
             if (wave == wv) {
 #pragma unroll
-                for (int i = 0; i < NDW; ++i)
+                for (int i = 0; i < 5; ++i)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) red[i * 256 + (4 * g + r) * 16 + p] += accw[i][r];
+                    for (int r = 0; r < 4; ++r) red[tiles[i] * 256 + (4 * g + r) * 16 + p] += accw[i][r];
             }
             __syncthreads();
         }
-        float* outp = a.part + (size_t)blockIdx.x * (NDW * 256);
-        for (int u = threadIdx.x; u < NDW * 256; u += BLOCK) outp[u] = red[u];
-        return;
-    }
-    // per-lane sums -> per-channel sums over the 16 edge lanes; lane p == 0 of group g owns channels 4g..4g+3
-    float (*rw)[3][2][16] = reinterpret_cast<float (*)[3][2][16]>(red);
+    } else {
+        // L1: g2 -> group 0.  L2: g1 -> group 0.  L3: pe lo, pe hi -> groups 0, 1.
+        float (*rw)[3][2][16] = reinterpret_cast<float (*)[3][2][16]>(red);
 #pragma unroll
-    for (int q = 0; q < 3; ++q)
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v1 = s1[q][r], v2 = s2[q][r];
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) { v1 += __shfl_xor(v1, off, WAVE); v2 += __shfl_xor(v2, off, WAVE); }
+                if (p == 0) { rw[wave][q][0][4 * g + r] = v1; rw[wave][q][1][4 * g + r] = v2; }
+            }
+    }
+}
+
+// WeightNet branch: VI -> w1 (8) -> w2 (8) -> w3 (C_mid), ReLU each.
+//   red (LEVEL < 4): groups {L1: w3 -> 1 | L2: w2 -> 1 | L3: w1 -> 2};   LEVEL 4: dW tiles 2, 5, 7.
+template <int LEVEL>
+__device__ __forceinline__ void weightnet_branch(const ChainBwdArgs& a, const float (*cf)[NCONST][16], const float4* wl,
+                                                 float* red, float* tb, long long t0, long long tstride) {
+    const ChainArgs& f = a.f;
+    const int lane = lane_id(), wave = wave_id(), p = lane & 15, g = lane >> 4;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const long long ntiles = f.E / 16;
+    const TileIO io{a, p, g, ntiles};
+    f32x4 s1 = zero4, s2 = zero4;
+    f32x4 accw[3] = {zero4, zero4, zero4};                        // w1, w2, w3
+    long long t = t0;
+    f32x4 x = io.load_x(t);
+    for (; t < ntiles; t += tstride) {
+        asm volatile("" ::: "memory");
+        const f32x4 x_next = io.load_x(t + tstride);
+        const f32x4 dwv = io.load_grad(a.dw, t, f.cm);
+        const f32x4 ac_a1 = mm(wl, 2, lane, x, zero4);
+        const f32x4 y_a1 = relu4(pre_of(ac_a1, cf[S_W1], g));
+        const f32x4 ac_a2 = mm(wl, 5, lane, y_a1, zero4);
+        const f32x4 y_a2 = relu4(pre_of(ac_a2, cf[S_W2], g));
+        const f32x4 ac_w = mm(wl, 7, lane, y_a2, zero4);
+        const f32x4 g_w = mask_pos(dwv, pre_of(ac_w, cf[S_W3], g));
+        if (LEVEL == 1) {
+            s1 += g_w; s2 += g_w * ac_w;
+        } else {
+            const f32x4 dz_w = bn_dz(g_w, ac_w, cf[S_W3], g);
+            if (LEVEL == 4) {
+                put_tile(tb + 0 * 16 * TT, dz_w, p, g);
+                put_tile(tb + 1 * 16 * TT, y_a2, p, g);
+                accw[2] = outer(tb + 0 * 16 * TT, tb + 1 * 16 * TT, p, g, accw[2]);
+            }
+            const f32x4 g_a2 = mask_pos(mm(wl, 9, lane, dz_w, zero4), y_a2);
+            if (LEVEL == 2) {
+                s1 += g_a2; s2 += g_a2 * ac_a2;
+            } else {
+                const f32x4 dz_a2 = bn_dz(g_a2, ac_a2, cf[S_W2], g);
+                if (LEVEL == 4) {
+                    put_tile(tb + 0 * 16 * TT, dz_a2, p, g);
+                    put_tile(tb + 1 * 16 * TT, y_a1, p, g);
+                    accw[1] = outer(tb + 0 * 16 * TT, tb + 1 * 16 * TT, p, g, accw[1]);
+                }
+                const f32x4 g_a1 = mask_pos(mm(wl, 12, lane, dz_a2, zero4), y_a1);
+                if (LEVEL == 3) {
+                    s1 += g_a1; s2 += g_a1 * ac_a1;
+                } else {
+                    put_tile(tb + 0 * 16 * TT, bn_dz(g_a1, ac_a1, cf[S_W1], g), p, g);
+                    put_tile(tb + 1 * 16 * TT, x, p, g);
+                    accw[0] = outer(tb + 0 * 16 * TT, tb + 1 * 16 * TT, p, g, accw[0]);
+                }
+            }
+        }
+        x = x_next;
+    }
+    if (LEVEL == 4) {
+        const int tiles[3] = {2, 5, 7};
+        for (int wv = 0; wv < NWAVE; ++wv) {
+            if (wave == wv) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red[tiles[i] * 256 + (4 * g + r) * 16 + p] += accw[i][r];
+            }
+            __syncthreads();
+        }
+    } else {
+        float (*rw)[3][2][16] = reinterpret_cast<float (*)[3][2][16]>(red);
+        const int q = LEVEL == 3 ? 2 : 1;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            float v1 = s1[q][r], v2 = s2[q][r];
+            float v1 = s1[r], v2 = s2[r];
 #pragma unroll
             for (int off = 1; off < 16; off <<= 1) { v1 += __shfl_xor(v1, off, WAVE); v2 += __shfl_xor(v2, off, WAVE); }
             if (p == 0) { rw[wave][q][0][4 * g + r] = v1; rw[wave][q][1][4 * g + r] = v2; }
         }
+    }
+}
+
+// workgroup b of the launch: branch and rank among the workgroups of its branch; NG of every 8 workgroups take
+// the guidance branch (PCF_CHAIN_BWD_SPLIT, chosen per pass by measurement)
+template <int NG> __device__ __host__ inline bool is_guidance_block(int b) { return (b & 7) < NG; }
+template <int NG> __device__ __host__ inline int branch_rank(int b) {
+    return is_guidance_block<NG>(b) ? (b >> 3) * NG + (b & 7) : (b >> 3) * (8 - NG) + (b & 7) - NG;
+}
+template <int NG> __host__ inline int branch_blocks(int grid, bool guidance) {       // grid is a multiple of 8
+    return guidance ? (grid >> 3) * NG : (grid >> 3) * (8 - NG);
+}
+#ifndef PCF_SPLIT_L123
+#define PCF_SPLIT_L123 5
+#endif
+#ifndef PCF_SPLIT_L4
+#define PCF_SPLIT_L4 5
+#endif
+template <int LEVEL> struct SplitOf { static constexpr int NG = LEVEL == 4 ? PCF_SPLIT_L4 : PCF_SPLIT_L123; };
+
+template <int LEVEL>
+__global__ __launch_bounds__(BLOCK) void pcf_chain_bwd_kernel(const ChainBwdArgs a, int grid8) {
+    __shared__ __align__(16) float cf[NSLOT][NCONST][16];
+    __shared__ float4 wl[NFRAG * WAVE];
+    __shared__ float red[LEVEL == 4 ? NDW * 256 : NWAVE * 96];
+    __shared__ __align__(16) float tbuf[LEVEL == 4 ? NWAVE * 3 * 16 * TT : 4];
+    __shared__ int gi[NWAVE][16];
+    stage_consts(a, cf, LEVEL);
+    stage_weights(a, wl);
+    for (int t = threadIdx.x; t < (LEVEL == 4 ? NDW * 256 : NWAVE * 96); t += BLOCK) red[t] = 0.f;
+    __syncthreads();
+    const int wave = wave_id();
+    float* tb = LEVEL == 4 ? tbuf + wave * 3 * 16 * TT : tbuf;
+    constexpr int NG = SplitOf<LEVEL>::NG;
+    const int rank = branch_rank<NG>(blockIdx.x);
+    if (is_guidance_block<NG>(blockIdx.x))
+        guidance_branch<LEVEL>(a, cf, wl, red, tb, gi[wave], (long long)rank * NWAVE + wave, (long long)grid8 * NG * NWAVE);
+    else
+        weightnet_branch<LEVEL>(a, cf, wl, red, tb, (long long)rank * NWAVE + wave, (long long)grid8 * (8 - NG) * NWAVE);
+    if (LEVEL == 4) {
+        float* outp = a.part + (size_t)blockIdx.x * (NDW * 256);
+        for (int u = threadIdx.x; u < NDW * 256; u += BLOCK) outp[u] = red[u];
+        return;
+    }
     __syncthreads();
     if (threadIdx.x < 96) {
+        const float (*rw)[3][2][16] = reinterpret_cast<const float (*)[3][2][16]>(red);
         const int q = threadIdx.x / 32, which = (threadIdx.x >> 4) & 1, c = threadIdx.x & 15;
         float tsum = 0.f;
 #pragma unroll
@@ -350,7 +452,7 @@ __global__ __launch_bounds__(BLOCK) void pcf_chain_bwd_kernel(const ChainBwdArgs
 }
 
 // Sums of one pass: up to three groups of 16 channels, each a slice [chan0, chan0 + count) of one layer.
-struct BwdFinGroup { float* dbeta; float* dgamma; float* gmean; float* gxmean; int chan0; int count; };
+struct BwdFinGroup { float* dbeta; float* dgamma; float* gmean; float* gxmean; const float* mean; const float* rstd; const float* bias; int chan0; int count; };
 struct BwdFinArgs { BwdFinGroup g[3]; const float* part; int nblocks; long long R; };
 
 __global__ __launch_bounds__(1024) void chain_bwd_finalize_kernel(const BwdFinArgs f) {
@@ -378,11 +480,14 @@ __global__ __launch_bounds__(1024) void chain_bwd_finalize_kernel(const BwdFinAr
             for (int sl = 0; sl < 10; ++sl) sums[which] += sh[sl][q * 32 + which * 16 + c];
         const BwdFinGroup& g = f.g[q];
         if (g.dbeta && c < g.count) {
+            // sums[1] = sum g * acc with acc the raw accumulator; xhat = acc * rstd + (b - mean) * rstd
             const int o = g.chan0 + c;
+            const double rs = (double)g.rstd[o], x0 = ((double)g.bias[o] - (double)g.mean[o]) * rs;
+            const double dgamma = rs * sums[1] + x0 * sums[0];
             g.dbeta[o] = (float)sums[0];
-            g.dgamma[o] = (float)sums[1];
+            g.dgamma[o] = (float)dgamma;
             g.gmean[o] = (float)(sums[0] / (double)f.R);
-            g.gxmean[o] = (float)(sums[1] / (double)f.R);
+            g.gxmean[o] = (float)(dgamma / (double)f.R);
         }
     }
 }
@@ -445,8 +550,8 @@ int pcf_hip_pcf_chain_backward(const float* vi, const int64_t* idx, const float*
     PCF_REQUIRE(E >= 0 && rows_per_batch > 0 && N >= 0, "pcf_chain_backward: bad sizes");
     if (cv < 1 || cv > CV || g < 1 || g > CG || heads < 1 || heads > CHD || cm < 1 || cm > CMX)
         return fail(PCF_E_UNSUPPORTED, "pcf_chain_backward: widths outside the fused kernel (cv=%d<=12, g=%d<=32, heads=%d<=8, cm=%d<=16)", cv, g, heads, cm);
-    if (K < 1 || K > 16 || (K & (K - 1)) != 0 || E % 16 != 0 || E % rows_per_batch != 0)
-        return fail(PCF_E_UNSUPPORTED, "pcf_chain_backward: K must be a power of two <= 16 and the edge count a multiple of 16 (K=%d)", K);
+    if (K < 1 || K > 16 || (K & (K - 1)) != 0 || E % 16 != 0 || E % rows_per_batch != 0 || rows_per_batch < 16)
+        return fail(PCF_E_UNSUPPORTED, "pcf_chain_backward: K must be a power of two <= 16, the edge count a multiple of 16 and >= 16 edges per batch (K=%d)", K);
     PCF_REQUIRE(W && b && gamma && beta && stats && du && dW && db && dgamma && dbeta, "pcf_chain_backward: null pointer");
     hipStream_t s = (hipStream_t)stream;
     const int couts[6] = {g, CH, heads, CH, CH, cm};
@@ -483,26 +588,29 @@ int pcf_hip_pcf_chain_backward(const float* vi, const int64_t* idx, const float*
         a.gmean[l] = means + l * 64; a.gxmean[l] = means + (6 + l) * 64;
     }
     a.dscore = dscore; a.dw = dw; a.du = du;
-    const int grid = chain_grid(E);
+    // both branches need at least one workgroup; a multiple of 8 keeps the 5 : 3 split exact
+    const int grid = std::max(8, (chain_grid(E) + 7) / 8 * 8);
     for (int pass = 0; pass < 3; ++pass) {
-        if (pass == 0) hipLaunchKernelGGL(pcf_chain_bwd_kernel<1>, dim3(grid), dim3(BLOCK), 0, s, a);
-        else if (pass == 1) hipLaunchKernelGGL(pcf_chain_bwd_kernel<2>, dim3(grid), dim3(BLOCK), 0, s, a);
-        else hipLaunchKernelGGL(pcf_chain_bwd_kernel<3>, dim3(grid), dim3(BLOCK), 0, s, a);
+        if (pass == 0) hipLaunchKernelGGL(pcf_chain_bwd_kernel<1>, dim3(grid), dim3(BLOCK), 0, s, a, grid / 8);
+        else if (pass == 1) hipLaunchKernelGGL(pcf_chain_bwd_kernel<2>, dim3(grid), dim3(BLOCK), 0, s, a, grid / 8);
+        else hipLaunchKernelGGL(pcf_chain_bwd_kernel<3>, dim3(grid), dim3(BLOCK), 0, s, a, grid / 8);
         if (int e = check_launch("pcf_chain_backward pass")) return e;
         BwdFinArgs fa{};
         fa.part = a.part; fa.nblocks = grid; fa.R = E;
         auto set = [&](int q, int layer, int chan0, int count) {
             fa.g[q].dbeta = dbeta[layer]; fa.g[q].dgamma = dgamma[layer];
             fa.g[q].gmean = means + layer * 64; fa.g[q].gxmean = means + (6 + layer) * 64;
+            fa.g[q].mean = stats + layer * 64; fa.g[q].rstd = stats + (6 + layer) * 64; fa.g[q].bias = b[layer];
             fa.g[q].chan0 = chan0; fa.g[q].count = count;
         };
         if (pass == 0) { set(0, L_G2, 0, heads); set(1, L_W3, 0, cm); }
         else if (pass == 1) { set(0, L_G1, 0, CH); set(1, L_W2, 0, CH); }
         else { set(0, L_PE, 0, std::min(g, 16)); set(1, L_PE, 16, std::max(g - 16, 0)); set(2, L_W1, 0, CH); }
+        // (guidance workgroups fill groups 0 [and 1 in pass 3], WeightNet workgroups group 1 [2 in pass 3]; the rest are zeros)
         hipLaunchKernelGGL(chain_bwd_finalize_kernel, dim3(1), dim3(1024), 0, s, fa);
         if (int e = check_launch("pcf_chain_backward finalize")) return e;
     }
-    hipLaunchKernelGGL(pcf_chain_bwd_kernel<4>, dim3(grid), dim3(BLOCK), 0, s, a);
+    hipLaunchKernelGGL(pcf_chain_bwd_kernel<4>, dim3(grid), dim3(BLOCK), 0, s, a, grid / 8);
     if (int e = check_launch("pcf_chain_backward final pass")) return e;
     BwdParamArgs pa{};
     pa.part = a.part; pa.nblocks = grid; pa.cv = cv; pa.g = g; pa.heads = heads; pa.cm = cm;

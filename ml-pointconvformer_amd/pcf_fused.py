@@ -516,10 +516,10 @@ class _PCFChain(torch.autograd.Function):
         return (None, None, None, None, None, du, dfx, *grads)
 
 
-def pcf_chain_supported(cv, g, heads, cm, K, hidden_ok, n_edges):
+def pcf_chain_supported(cv, g, heads, cm, K, hidden_ok, n_edges, edges_per_batch=16):
     """Shapes the fused MFMA chain covers: a neighbourhood must fit one 16-edge tile."""
     return hidden_ok and 1 <= cv <= 12 and 1 <= g <= 32 and 1 <= heads <= 8 and 1 <= cm <= 16 \
-        and 1 <= K <= 16 and (K & (K - 1)) == 0 and n_edges % 16 == 0
+        and 1 <= K <= 16 and (K & (K - 1)) == 0 and n_edges % 16 == 0 and edges_per_batch >= 16
 
 
 def pcf_chain(vi, idx, u, fx, layers, training, fused_backward=True):

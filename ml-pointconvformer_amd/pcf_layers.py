@@ -325,7 +325,8 @@ class PCFLayer(nn.Module):
         hidden_ok = gw[0].c.out_features == 8 and wn[0].c.out_features == 8 and wn[1].c.out_features == 8 \
             and gw[0].c.in_features == 2 * self.mlp_conv.c.out_features
         if not pcf_fused.pcf_chain_supported(wn_in.shape[-1], self.mlp_conv.c.out_features, gw[1].c.out_features,
-                                             wn[2].c.out_features, nei_inds.shape[2], hidden_ok, nei_inds.numel()):
+                                             wn[2].c.out_features, nei_inds.shape[2], hidden_ok, nei_inds.numel(),
+                                             nei_inds.shape[1] * nei_inds.shape[2]):
             return None
         return [(m.c, m.bn) for m in mods]
 
