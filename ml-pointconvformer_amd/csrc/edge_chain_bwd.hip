@@ -497,6 +497,7 @@ __global__ __launch_bounds__(1024) void chain_bwd_finalize_kernel(const BwdFinAr
 struct BwdParamArgs {
     const float* part; int nblocks;
     float* dW[6];
+    float* db[6];               // written as zeros (bias in front of a training-mode BatchNorm)
     int cv, g, heads, cm;
 };
 
@@ -515,6 +516,11 @@ __global__ __launch_bounds__(1024) void chain_bwd_params_kernel(const BwdParamAr
     for (; p < f.nblocks; p += 16) a0 += f.part[(size_t)p * (NDW * 256) + e];
     sh[slice][threadIdx.x & 63] = (a0 + a1) + (a2 + a3);
     __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x >= 64 && threadIdx.x < 64 + 6 * 32) {
+        const int l = (threadIdx.x - 64) >> 5, o = (threadIdx.x - 64) & 31;
+        const int couts[6] = {f.g, CH, f.heads, CH, CH, f.cm};
+        if (o < couts[l]) f.db[l][o] = 0.f;
+    }
     if (threadIdx.x >= 64) return;
     float tot = 0.f;
 #pragma unroll
@@ -559,9 +565,8 @@ int pcf_hip_pcf_chain_backward(const float* vi, const int64_t* idx, const float*
     for (int l = 0; l < 6; ++l) {
         PCF_REQUIRE(W[l] && b[l] && gamma[l] && beta[l] && dW[l] && db[l] && dgamma[l] && dbeta[l],
                     "pcf_chain_backward: null parameter of layer %d", l);
-        // bias before a training-mode BatchNorm: the gradient is identically zero
-        if (hipMemsetAsync(db[l], 0, (size_t)couts[l] * 4, s) != hipSuccess) return fail(PCF_E_LAUNCH, "pcf_chain_backward: memset");
         if (E == 0) {
+            (void)hipMemsetAsync(db[l], 0, (size_t)couts[l] * 4, s);
             (void)hipMemsetAsync(dW[l], 0, (size_t)couts[l] * cins[l] * 4, s);
             (void)hipMemsetAsync(dgamma[l], 0, (size_t)couts[l] * 4, s);
             (void)hipMemsetAsync(dbeta[l], 0, (size_t)couts[l] * 4, s);
@@ -614,7 +619,7 @@ int pcf_hip_pcf_chain_backward(const float* vi, const int64_t* idx, const float*
     if (int e = check_launch("pcf_chain_backward final pass")) return e;
     BwdParamArgs pa{};
     pa.part = a.part; pa.nblocks = grid; pa.cv = cv; pa.g = g; pa.heads = heads; pa.cm = cm;
-    for (int l = 0; l < 6; ++l) pa.dW[l] = dW[l];
+    for (int l = 0; l < 6; ++l) { pa.dW[l] = dW[l]; pa.db[l] = db[l]; }
     hipLaunchKernelGGL(chain_bwd_params_kernel, dim3(NDW * 256 / 64), dim3(1024), 0, s, pa);
     return check_launch("pcf_chain_backward parameter reduction");
 }
