@@ -25,6 +25,22 @@ def test_header_symbols_exported():
         assert hasattr(lib, n), f'{n} declared in include/pcf_hip.h but not exported'
 
 
+def test_every_export_is_declared():
+    """The reverse direction: no `pcf_hip_*` entry point ships without a declaration (and a reference citation)
+    in the header."""
+    import shutil
+    import subprocess
+    import pcf_cuda
+    nm = shutil.which('nm') or '/opt/rocm/lib/llvm/bin/llvm-nm'
+    if not os.path.exists(nm):
+        pytest.skip('no nm in this image')
+    out = subprocess.run([nm, '-D', '--defined-only', pcf_cuda.library_path()], capture_output=True, text=True, check=True).stdout
+    exported = sorted({line.split()[-1] for line in out.splitlines() if line.split() and line.split()[-1].startswith('pcf_hip_')})
+    assert len(exported) >= 40
+    missing = [n for n in exported if n not in _declared()]
+    assert not missing, f'exported but not declared in include/pcf_hip.h: {missing}'
+
+
 def test_module_surface_matches_reference():
     import pcf_cuda
     # pcf_cuda.cpp:10-18
