@@ -410,9 +410,15 @@ static int make_plan(Plan& pl, bool backward, bool guided, int total, int K, int
     if ((per_pt + slack) * 4 > (size_t)LDS_MAX)
         return fail(PCF_E_UNSUPPORTED, "aggregate: one point needs %zu B of LDS (K=%d Ci=%d Ca=%d Cm=%d), limit %d",
                     (per_pt + slack) * 4, K, Ci, Ca, Cm, LDS_MAX);
-    int P = (int)((LDS_BUDGET / 4 - slack) / per_pt);
+    // Points per workgroup.  The backward kernel has three block-wide phases with the HBM latency of its staging
+    // exposed in each, so it wants resident workgroups more than amortisation: 4 points (one per wave, ~22 KB of
+    // LDS, 7 workgroups per CU) measured 122 us against 154 us with 8 points at N = 80k; the forward (one staging
+    // phase) is fastest with 8.
+    const int budget = backward ? 24 * 1024 : LDS_BUDGET;
+    const int pmax = backward ? NWAVE : 8;
+    int P = (int)((budget / 4 - slack) / per_pt);
     if (P < 1) P = 1;
-    if (P > 8) P = 8;
+    if (P > pmax) P = pmax;
     while (P > NWAVE && total / P < 1024) --P;
     pl.P = P;
     size_t off = r4((size_t)P * per_pt_idx);
