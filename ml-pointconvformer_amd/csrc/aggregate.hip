@@ -50,9 +50,13 @@ __device__ __forceinline__ int pow2_ceil_dev(int v) {
 // ---- phases shared by forward and backward -----------------------------------------------------
 // phase 0: neighbour table -> LDS as int32 row numbers into the flattened [B*N] input (-1 = skip),
 //          guidance tile -> LDS.
+// FX: the BASELINE layer shape (K = 16, Ci = 16, Ca = 0, H = 8; Cm = 16 through CM) as compile-time constants --
+// the generic kernels spend more instructions on loop control and index arithmetic than on the products.
+template <bool FX>
 __device__ __forceinline__ void stage_index_and_guidance(const AggArgs& a, int n0, int np, int* sIdx, float* sG) {
     const int tid = threadIdx.x;
-    const int K = a.K;
+    const int K = FX ? 16 : a.K;
+    const int H = FX ? 8 : a.H;
     for (int u = tid; u < np * K; u += BLOCK) {
         const int n = n0 + u / K;
         const int b = n / a.Nout;
@@ -60,18 +64,18 @@ __device__ __forceinline__ void stage_index_and_guidance(const AggArgs& a, int n
         sIdx[u] = (j >= 0 && j < a.N) ? (int)((int64_t)b * a.N + j) : -1;
     }
     if (a.guid) {
-        const int cnt = np * K * a.H;
-        const float* g = a.guid + (size_t)n0 * K * a.H;
+        const int cnt = np * K * H;
+        const float* g = a.guid + (size_t)n0 * K * H;
         for (int u = tid; u < cnt; u += BLOCK) sG[u] = g[u];
     }
 }
 
 // phase 1: gathered rows (optionally head-modulated), appended features and weights -> LDS.
-template <bool VROW, bool MODULATE>
+template <bool VROW, bool MODULATE, bool FX, int FXTS>
 __device__ __forceinline__ void stage_tiles(const AggArgs& a, int n0, int np, const int* sIdx, const float* sG,
                                             float* sT, float* sW, int Cm) {
     const int tid = threadIdx.x;
-    const int K = a.K, Ci = a.Ci, Ca = a.Ca, TS = a.TS, H = a.H;
+    const int K = FX ? 16 : a.K, Ci = FX ? 16 : a.Ci, Ca = FX ? 0 : a.Ca, TS = FX ? FXTS : a.TS, H = FX ? 8 : a.H;
     const HeadMod hm(H > 0 ? H : 1);
     if (VROW) {
         const int ci4 = Ci >> 2;
@@ -137,7 +141,7 @@ __device__ __forceinline__ void stage_tiles(const AggArgs& a, int n0, int np, co
 
 // ---- forward ------------------------------------------------------------------------------------
 // CM > 0: compile-time Cm (multiple of 4 -> four m per lane, else one); CM == 0: run-time Cm.
-template <int CM, bool VROW>
+template <int CM, bool VROW, bool FX = false>
 __global__ __launch_bounds__(BLOCK) void agg_fwd_kernel(const AggArgs a) {
     extern __shared__ __align__(16) float smem[];
     int* sIdx = reinterpret_cast<int*>(smem);
@@ -146,12 +150,12 @@ __global__ __launch_bounds__(BLOCK) void agg_fwd_kernel(const AggArgs a) {
     float* sW = smem + a.offW;
     const int n0 = blockIdx.x * a.P;
     const int np = min(a.P, a.total - n0);
-    const int K = a.K, CT = a.Ci + a.Ca, TS = a.TS;
+    const int K = FX ? 16 : a.K, CT = FX ? 16 : a.Ci + a.Ca, TS = FX ? 16 : a.TS;
     const int Cm = CM ? CM : a.Cm;
 
-    stage_index_and_guidance(a, n0, np, sIdx, sG);
+    stage_index_and_guidance<FX>(a, n0, np, sIdx, sG);
     __syncthreads();
-    stage_tiles<VROW, true>(a, n0, np, sIdx, sG, sT, sW, Cm);
+    stage_tiles<VROW, true, FX, 16>(a, n0, np, sIdx, sG, sT, sW, Cm);
     __syncthreads();
 
     const int lane = lane_id();
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(BLOCK) void agg_fwd_kernel(const AggArgs a) {
 }
 
 // ---- backward -----------------------------------------------------------------------------------
-template <int CM, bool VROW, bool SCATTER_ATOMIC>
+template <int CM, bool VROW, bool SCATTER_ATOMIC, bool FX = false>
 __global__ __launch_bounds__(BLOCK) void agg_bwd_kernel(const AggArgs a) {
     extern __shared__ __align__(16) float smem[];
     int* sIdx = reinterpret_cast<int*>(smem);
@@ -195,14 +199,15 @@ __global__ __launch_bounds__(BLOCK) void agg_bwd_kernel(const AggArgs a) {
     const int tid = threadIdx.x;
     const int n0 = blockIdx.x * a.P;
     const int np = min(a.P, a.total - n0);
-    const int K = a.K, Ci = a.Ci, Ca = a.Ca, CT = Ci + Ca, TS = a.TS, GS = a.GS, H = a.H;
+    const int K = FX ? 16 : a.K, Ci = FX ? 16 : a.Ci, Ca = FX ? 0 : a.Ca, CT = Ci + Ca, TS = FX ? 20 : a.TS,
+              GS = FX ? 20 : a.GS, H = FX ? 8 : a.H;
     const int Cm = CM ? CM : a.Cm;
     const bool guided = a.guid != nullptr;
     const HeadMod hm(H > 0 ? H : 1);
 
-    stage_index_and_guidance(a, n0, np, sIdx, sG);
+    stage_index_and_guidance<FX>(a, n0, np, sIdx, sG);
     __syncthreads();
-    stage_tiles<VROW, false>(a, n0, np, sIdx, sG, sT, sW, Cm);
+    stage_tiles<VROW, false, FX, 20>(a, n0, np, sIdx, sG, sT, sW, Cm);
     {   // grad_out: contiguous [np*CT*Cm] run -> rows of stride GS
         const float* src = a.gout + (size_t)n0 * CT * Cm;
         if (CM > 0 && (CM & 3) == 0 && VROW) {
@@ -377,6 +382,7 @@ struct Plan {
     int P, TS, GS, offG, offT, offD, offW, offO;
     size_t lds_bytes;
     bool vrow;
+    bool fixed_shape;      // K = 16, Ci = 16, Ca = 0, H = 8, Cm = 16, guided, 16-byte rows
     int cm_t;   // template Cm (0 = run-time)
 };
 
@@ -398,6 +404,8 @@ static int make_plan(Plan& pl, bool backward, bool guided, int total, int K, int
         pl.TS = backward ? (CT | 1) : CT;
     }
     pl.GS = (pl.cm_t >= 4) ? Cm + 4 : Cm;
+    pl.fixed_shape = guided && pl.vrow && pl.cm_t == 16 && K == 16 && Ci == 16 && Ca == 0 && H == 8 &&
+                     pl.TS == (backward ? 20 : 16) && pl.GS == 20;
     auto r4 = [](size_t v) { return (v + 3) / 4 * 4; };
     const size_t per_pt_idx = K;
     const size_t per_pt_g = guided ? (size_t)K * H : 0;
@@ -448,6 +456,7 @@ static int launch_fwd(const AggArgs& a, const Plan& pl, hipStream_t s) {
 #define PCF_FWD(CMV)                                                                   \
     return pl.vrow ? launch(agg_fwd_kernel<CMV, true>, a, pl, s, "aggregate forward")  \
                    : launch(agg_fwd_kernel<CMV, false>, a, pl, s, "aggregate forward")
+    if (pl.fixed_shape) return launch(agg_fwd_kernel<16, true, true>, a, pl, s, "aggregate forward");
     switch (pl.cm_t) {
         case 1: PCF_FWD(1);
         case 4: return launch(agg_fwd_kernel<4, true>, a, pl, s, "aggregate forward");
@@ -464,6 +473,7 @@ static int launch_bwd_mode(const AggArgs& a, const Plan& pl, hipStream_t s) {
 #define PCF_BWD(CMV)                                                                            \
     return pl.vrow ? launch(agg_bwd_kernel<CMV, true, ATOMIC>, a, pl, s, "aggregate backward")  \
                    : launch(agg_bwd_kernel<CMV, false, ATOMIC>, a, pl, s, "aggregate backward")
+    if (pl.fixed_shape) return launch(agg_bwd_kernel<16, true, ATOMIC, true>, a, pl, s, "aggregate backward");
     switch (pl.cm_t) {
         case 1: PCF_BWD(1);
         case 4: return launch(agg_bwd_kernel<4, true, ATOMIC>, a, pl, s, "aggregate backward");
