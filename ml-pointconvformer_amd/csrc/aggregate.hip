@@ -422,9 +422,8 @@ static int make_plan(Plan& pl, bool backward, bool guided, int total, int K, int
     // exposed in each, so it wants resident workgroups more than amortisation: 4 points (one per wave, ~22 KB of
     // LDS, 7 workgroups per CU) measured 122 us against 154 us with 8 points at N = 80k; the forward (one staging
     // phase) is fastest with 8.
-    const int budget = backward ? 24 * 1024 : LDS_BUDGET;
     const int pmax = backward ? NWAVE : 8;
-    int P = (int)((budget / 4 - slack) / per_pt);
+    int P = (int)((LDS_BUDGET / 4 - slack) / per_pt);
     if (P < 1) P = 1;
     if (P > pmax) P = pmax;
     while (P > NWAVE && total / P < 1024) --P;

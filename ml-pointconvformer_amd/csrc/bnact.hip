@@ -79,10 +79,11 @@ __global__ __launch_bounds__(BLOCK) void col_partials_kernel(const float* __rest
     }
 }
 
-// combine partials: one 1024-thread workgroup per 64 columns x 16 slices of the partial list, two
+// combine partials: one 1024-thread workgroup per 16 columns x 64 slices of the partial list, two
 // independent fp64 chains per slice and sum (a serial walk of ~300 partials is ~20 us of load latency)
 constexpr int FIN_THREADS = 1024;
-constexpr int FIN_SLICES = FIN_THREADS / 64;
+constexpr int FIN_COLS = 16;
+constexpr int FIN_SLICES = FIN_THREADS / FIN_COLS;
 template <int MODE>
 __global__ __launch_bounds__(FIN_THREADS) void col_finalize_kernel(const float* __restrict__ part, int nblocks, long long R, int C,
                                                                    float eps, float momentum, float* __restrict__ running_mean,
@@ -90,8 +91,8 @@ __global__ __launch_bounds__(FIN_THREADS) void col_finalize_kernel(const float* 
                                                                    float* __restrict__ o2, float* __restrict__ m1,
                                                                    float* __restrict__ m2) {
     __shared__ double sa[FIN_THREADS], sb[FIN_THREADS];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int slice = threadIdx.x >> 6;
+    const int c = blockIdx.x * FIN_COLS + (threadIdx.x & (FIN_COLS - 1));
+    const int slice = threadIdx.x / FIN_COLS;
     double a = 0.0, b = 0.0;
     if (c < C) {
         double a1 = 0.0, b1 = 0.0;
@@ -110,10 +111,10 @@ __global__ __launch_bounds__(FIN_THREADS) void col_finalize_kernel(const float* 
     }
     sa[threadIdx.x] = a; sb[threadIdx.x] = b;
     __syncthreads();
-    if (threadIdx.x < 64 && c < C) {
+    if (threadIdx.x < FIN_COLS && c < C) {
         a = 0.0; b = 0.0;
-#pragma unroll
-        for (int sl = 0; sl < FIN_SLICES; ++sl) { a += sa[sl * 64 + threadIdx.x]; b += sb[sl * 64 + threadIdx.x]; }
+#pragma unroll 8
+        for (int sl = 0; sl < FIN_SLICES; ++sl) { a += sa[sl * FIN_COLS + threadIdx.x]; b += sb[sl * FIN_COLS + threadIdx.x]; }
         const double n = (double)R;
         if (MODE == 0) {
             const double mean = a / n;
@@ -227,7 +228,7 @@ int pcf_hip_bnact_stats(const float* z, long long R, int C, float eps, float mom
     const long long rpb = (R + nb - 1) / nb;
     hipLaunchKernelGGL(col_partials_kernel<0>, dim3(nb), dim3(BLOCK), 0, s, z, nullptr, R, C, tx_for(C), rpb, nullptr, nullptr,
                        nullptr, nullptr, 0, part);
-    hipLaunchKernelGGL(col_finalize_kernel<0>, dim3(ceil_div(C, 64)), dim3(FIN_THREADS), 0, s, part, nb, R, C, eps, momentum,
+    hipLaunchKernelGGL(col_finalize_kernel<0>, dim3(ceil_div(C, FIN_COLS)), dim3(FIN_THREADS), 0, s, part, nb, R, C, eps, momentum,
                        running_mean, running_var, mean_out, rstd_out, nullptr, nullptr);
     return check_launch("bnact statistics");
 }
@@ -269,7 +270,7 @@ int pcf_hip_bnact_backward(const float* z, const float* dy, long long R, int C, 
         const long long rpb = (R + nb - 1) / nb;
         hipLaunchKernelGGL(col_partials_kernel<1>, dim3(nb), dim3(BLOCK), 0, s, z, dy, R, C, tx_for(C), rpb, mean, rstd, gamma,
                            beta, act, part);
-        hipLaunchKernelGGL(col_finalize_kernel<1>, dim3(ceil_div(C, 64)), dim3(FIN_THREADS), 0, s, part, nb, R, C, 0.f, 0.f, nullptr,
+        hipLaunchKernelGGL(col_finalize_kernel<1>, dim3(ceil_div(C, FIN_COLS)), dim3(FIN_THREADS), 0, s, part, nb, R, C, 0.f, 0.f, nullptr,
                            nullptr, dbeta, dgamma, m1, m2);
         if (int e = check_launch("bnact backward reductions")) return e;
         if (!batch_stats) { m1 = nullptr; m2 = nullptr; }

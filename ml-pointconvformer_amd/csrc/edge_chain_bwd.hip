@@ -456,28 +456,27 @@ struct BwdFinGroup { float* dbeta; float* dgamma; float* gmean; float* gxmean; c
 struct BwdFinArgs { BwdFinGroup g[3]; const float* part; int nblocks; long long R; };
 
 __global__ __launch_bounds__(1024) void chain_bwd_finalize_kernel(const BwdFinArgs f) {
-    __shared__ double sh[10][96];
-    const int v = threadIdx.x % 96, slice = threadIdx.x / 96;
-    if (slice < 10) {
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    // one workgroup per group: 32 values x 32 slices of the partial list, two fp64 chains per slice
+    __shared__ double sh[32][32];
+    const int gq = blockIdx.x;
+    const int v = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    {
+        double a0 = 0.0, a1 = 0.0;
         int p = slice;
-        for (; p + 30 < f.nblocks; p += 40) {
-            a0 += (double)f.part[(size_t)p * 96 + v];
-            a1 += (double)f.part[(size_t)(p + 10) * 96 + v];
-            a2 += (double)f.part[(size_t)(p + 20) * 96 + v];
-            a3 += (double)f.part[(size_t)(p + 30) * 96 + v];
+        for (; p + 32 < f.nblocks; p += 64) {
+            a0 += (double)f.part[(size_t)p * 96 + gq * 32 + v];
+            a1 += (double)f.part[(size_t)(p + 32) * 96 + gq * 32 + v];
         }
-        for (; p < f.nblocks; p += 10) a0 += (double)f.part[(size_t)p * 96 + v];
-        sh[slice][v] = (a0 + a1) + (a2 + a3);
+        if (p < f.nblocks) a0 += (double)f.part[(size_t)p * 96 + gq * 32 + v];
+        sh[slice][v] = a0 + a1;
     }
     __syncthreads();
-    if (threadIdx.x < 48) {
-        const int q = threadIdx.x >> 4, c = threadIdx.x & 15;
+    if (threadIdx.x < 16) {
+        const int q = gq, c = threadIdx.x;
         double sums[2] = {0.0, 0.0};
 #pragma unroll
         for (int which = 0; which < 2; ++which)
-#pragma unroll
-            for (int sl = 0; sl < 10; ++sl) sums[which] += sh[sl][q * 32 + which * 16 + c];
+            for (int sl = 0; sl < 32; ++sl) sums[which] += sh[sl][which * 16 + c];
         const BwdFinGroup& g = f.g[q];
         if (g.dbeta && c < g.count) {
             // sums[1] = sum g * acc with acc the raw accumulator; xhat = acc * rstd + (b - mean) * rstd
@@ -612,7 +611,7 @@ int pcf_hip_pcf_chain_backward(const float* vi, const int64_t* idx, const float*
         else if (pass == 1) { set(0, L_G1, 0, CH); set(1, L_W2, 0, CH); }
         else { set(0, L_PE, 0, std::min(g, 16)); set(1, L_PE, 16, std::max(g - 16, 0)); set(2, L_W1, 0, CH); }
         // (guidance workgroups fill groups 0 [and 1 in pass 3], WeightNet workgroups group 1 [2 in pass 3]; the rest are zeros)
-        hipLaunchKernelGGL(chain_bwd_finalize_kernel, dim3(1), dim3(1024), 0, s, fa);
+        hipLaunchKernelGGL(chain_bwd_finalize_kernel, dim3(3), dim3(1024), 0, s, fa);
         if (int e = check_launch("pcf_chain_backward finalize")) return e;
     }
     hipLaunchKernelGGL(pcf_chain_bwd_kernel<4>, dim3(grid), dim3(BLOCK), 0, s, a, grid / 8);

@@ -42,6 +42,6 @@ int rowlin_mfma_stats(const RowLin& a, int grid, hipStream_t s);
 int rowlin_mfma_forward(const RowLin& a, hipStream_t s);
 int rowlin_mfma_bwd_reduce(const RowLin& a, int grid, hipStream_t s);
 int rowlin_mfma_bwd_apply(const RowLin& a, int grid, hipStream_t s);
-int rowlin_mfma_grid(long long R);
+int rowlin_mfma_grid(long long R, int Cin);
 
 }  // namespace pcf

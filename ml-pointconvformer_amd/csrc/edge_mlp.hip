@@ -681,7 +681,7 @@ int pcf_hip_rowlin_bn_stats_ex(const float* x, long long R, int Cin, const float
     int rc = PCF_OK;
     int nparts = grid;
     if (rowlin_mfma_supported(a)) {
-        nparts = rowlin_mfma_grid(R);
+        nparts = rowlin_mfma_grid(R, Cin);
         rc = rowlin_mfma_stats(a, nparts, s);
     } else {
         PCF_CIN_SWITCH(CT, rc = launch_rowlin(rowlin_stats_kernel<C>, a, grid, lds_stats(C), s, "per-edge linear: BN statistics"));
@@ -772,7 +772,7 @@ int pcf_hip_rowlin_backward_ex(const float* x, const float* dy, long long R, int
     a.vec_y = (Cout % 4 == 0) && aligned16(dy);
     int rc = PCF_OK;
     const bool mfma = rowlin_mfma_supported(a);
-    const int nparts = mfma ? rowlin_mfma_grid(R) : grid;
+    const int nparts = mfma ? rowlin_mfma_grid(R, Cin) : grid;
     if (bn) {
         // dgamma / dbeta (and, with batch statistics, the two means the dz formula needs)
         if (mfma) rc = rowlin_mfma_bwd_reduce(a, nparts, s);

@@ -429,9 +429,14 @@ bool rowlin_mfma_supported(const RowLin& a) {
 
 // A wave keeps one 16-row tile of loads in flight, so the latency hiding has to come from resident waves:
 // up to 2048 workgroups = 8 waves per SIMD (the kernels need 32-68 VGPRs).
-int rowlin_mfma_grid(long long R) {
+// A wave keeps one 16-row tile of loads in flight, so the latency hiding comes from resident waves: up to 2048
+// workgroups.  Against that, every workgroup pays a fixed prologue and (backward) writes a Cout x 16*TI partial of
+// dW -- 16 KB at Cin = 64 -- so wide-input layers get TI tiles per wave: at R = 80k, Cin = 64 that is 313
+// workgroups (24 us) instead of 1250 (32 us), while the 8..16-wide per-edge layers keep one tile per wave.
+int rowlin_mfma_grid(long long R, int Cin) {
     const long long tiles = (R + 15) / 16;
-    return (int)std::max<long long>(1, std::min<long long>((tiles + NWAVE - 1) / NWAVE, 2048));
+    const long long per_wg = (long long)NWAVE * tiles_of(Cin);
+    return (int)std::max<long long>(1, std::min<long long>((tiles + per_wg - 1) / per_wg, 2048));
 }
 
 #define PCF_TILE_SWITCH(KERNEL, GRID)                                                                              \
@@ -453,7 +458,7 @@ int rowlin_mfma_stats(const RowLin& a, int grid, hipStream_t s) {
     return check_launch("per-edge linear (MFMA): BN statistics");
 }
 int rowlin_mfma_forward(const RowLin& a, hipStream_t s) {
-    PCF_TILE_SWITCH(rowlin_mfma_fwd_kernel, rowlin_mfma_grid(a.R));
+    PCF_TILE_SWITCH(rowlin_mfma_fwd_kernel, rowlin_mfma_grid(a.R, a.Cin));
     return check_launch("per-edge linear (MFMA) forward");
 }
 int rowlin_mfma_bwd_reduce(const RowLin& a, int grid, hipStream_t s) {
