@@ -100,7 +100,9 @@ def test_pcf_layer_matches_reference(device, name, ci, co, cm, heads, mode):
     _run(layer, g, device, ['dense_feats'], PCF_ORDER)
 
 
-@pytest.mark.parametrize('B,N,K,cm,heads,gfl', [(2, 3000, 16, 16, 8, 32), (1, 4096, 8, 8, 4, 16), (3, 1000, 4, 16, 8, 20)])
+# (4, 1001, 4): 4004 edges per cloud, so batch boundaries fall inside 16-edge tiles
+@pytest.mark.parametrize('B,N,K,cm,heads,gfl', [(2, 3000, 16, 16, 8, 32), (1, 4096, 8, 8, 4, 16), (3, 1000, 4, 16, 8, 20),
+                                                (4, 1001, 4, 4, 2, 8), (1, 64, 2, 16, 8, 32)])
 def test_fused_edge_chain_backward_against_layerwise(device, B, N, K, cm, heads, gfl):
     """The four-pass recompute backward (edge_chain_bwd.hip) against the layer-at-a-time kernels on a random
     layer: same forward, gradients of the features, of the per-point guidance term and of all 24 parameters."""
@@ -462,3 +464,53 @@ def test_wide_linear_bn_act_against_torch(device, rows, cin, cout, act, bn, trai
         torch.testing.assert_close(bn_d.bias.grad.cpu(), ref_bn.bias.grad.float(), rtol=3e-4, atol=3e-4 * sc)
         torch.testing.assert_close(bn_d.running_mean.cpu(), ref_bn.running_mean.float(), rtol=1e-5, atol=1e-6)
         torch.testing.assert_close(bn_d.running_var.cpu(), ref_bn.running_var.float(), rtol=1e-5, atol=1e-6)
+
+
+def test_fused_edge_chain_inference(device):
+    """eval(): the chain runs its single inference pass on the running statistics.  Against the layer-at-a-time
+    kernels, after one training step so the running statistics moved (they are compared too).  (PCFLayer needs the
+    12-channel VI input in the reference as well: mlp_conv is Linear_BN(12, .), layers.py:241.)"""
+    import pcf_layers
+    torch.manual_seed(3)
+    use_vi = True
+    B, N, K = 2, 777, 16
+    xyz = torch.rand(B, N, 3, device=device)
+    nrm = torch.nn.functional.normalize(torch.randn(B, N, 3, device=device), dim=-1)
+    nei = torch.cdist(xyz, xyz).topk(K, dim=-1, largest=False).indices.contiguous()
+    feats = torch.randn(B, N, 32, device=device)
+    outs = {}
+    for mode in ('fused', 'off'):
+        torch.manual_seed(21)
+        wn0 = 12 if use_vi else 3
+        layer = pcf_layers.PCFLayer(32, 64, cfg(USE_VI=use_vi, **CHAIN_MODES[mode]), weightnet=[wn0, 16], num_heads=8,
+                                    guidance_feat_len=32).to(device)
+        if use_vi:
+            assert (layer._chain_layers(torch.empty(B, N, K, wn0), nei) is not None) == (mode == 'fused')
+        layer.train()
+        layer(xyz, feats, nei, nrm)[0].sum().backward()
+        layer.eval()
+        with torch.no_grad():
+            outs[mode] = layer(xyz, feats, nei, nrm)[0]
+        rm = {n: b.clone() for n, b in layer.named_buffers() if 'running' in n}
+        outs[mode + '_rm'] = rm
+    torch.testing.assert_close(outs['fused'], outs['off'], rtol=1e-3, atol=1e-3)
+    for n, v in outs['fused_rm'].items():
+        torch.testing.assert_close(v, outs['off_rm'][n], rtol=1e-4, atol=1e-5, msg=lambda m, k=n: f'{k}: {m}')
+
+
+def test_edge_chain_rejects_what_it_does_not_cover(device):
+    """Shapes outside the fused kernels: the support predicate says no (callers fall back), and the C entry points
+    return PCF_E_UNSUPPORTED with a message instead of launching."""
+    import pcf_fused
+    assert not pcf_fused.pcf_chain_supported(12, 32, 8, 16, 32, True, 32 * 100)        # K > 16
+    assert not pcf_fused.pcf_chain_supported(12, 32, 8, 16, 12, True, 12 * 64)         # K not a power of two
+    assert not pcf_fused.pcf_chain_supported(12, 48, 8, 16, 16, True, 16 * 64)         # guidance width > 32
+    assert not pcf_fused.pcf_chain_supported(12, 32, 8, 16, 2, True, 2 * 4, edges_per_batch=8)
+    lin = [torch.nn.Linear(a, b).to(device) for a, b in [(12, 32), (64, 8), (8, 8), (12, 8), (8, 8), (8, 16)]]
+    bns = [torch.nn.BatchNorm1d(l.out_features).to(device) for l in lin]
+    vi = torch.randn(1, 8, 32, 12, device=device)
+    idx = torch.zeros(1, 8, 32, dtype=torch.long, device=device)
+    u = torch.randn(1, 8, 8, device=device)
+    fx = torch.randn(1, 8, 16, device=device)
+    with pytest.raises(RuntimeError, match='power of two'):
+        pcf_fused.pcf_chain(vi, idx, u, fx, list(zip(lin, bns)), True)
