@@ -15,6 +15,8 @@ def _call(fn, *args):
     return pcf_cuda._call(fn, *args)
 
 _LL = ctypes.c_longlong
+_Z = ctypes.c_size_t
+_F = ctypes.c_float
 
 
 def _sig(name, argtypes):
@@ -134,8 +136,6 @@ def vi_from_gathered(localized_xyz, gathered_norm, ctr_norm):
 # --------------------------------------------------------------------------------------------------
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2, 3
 ROWLIN_MAX_CHANNELS = 64
-_Z = ctypes.c_size_t
-_F = ctypes.c_float
 
 _rowlin_ws = getattr(_lib, 'pcf_hip_rowlin_workspace_bytes')
 _rowlin_ws.argtypes = [_I, _I]

@@ -274,13 +274,14 @@ class WeightNet(nn.Module):
 # --------------------------------------------------------------------------------------------------
 # layers
 # --------------------------------------------------------------------------------------------------
-def _edge_geometry(cfg_use_vi, ref_xyz, ref_norm, nei_inds, ctr_xyz, ctr_norm, vi_features):
+def _edge_geometry(cfg_use_vi, ref_xyz, ref_norm, nei_inds, ctr_xyz, ctr_norm, vi_features, want_rel=True):
     """-> (localized_xyz or None, weightNetInput).  One fused HIP kernel gathers the neighbour
-    coordinates / normals and emits the offsets and the 12-channel VI descriptor."""
+    coordinates / normals and emits the offsets (unless want_rel is False and the VI descriptor is produced)
+    and the 12-channel VI descriptor."""
     if cfg_use_vi and vi_features is not None:
         return None, vi_features
     rel, vi = pcf_fused.edge_geometry(ref_xyz, ref_norm if cfg_use_vi else None, nei_inds, ctr_xyz,
-                                      ctr_norm if cfg_use_vi else None)
+                                      ctr_norm if cfg_use_vi else None, want_rel=want_rel)
     return rel, (vi if cfg_use_vi else rel)
 
 
@@ -338,7 +339,7 @@ class PCFLayer(nn.Module):
         nei_inds = nei_inds.contiguous()
         feats_x = self.unary1(dense_feats)
         _, wn_in = _edge_geometry(self.cfg.USE_VI is True, dense_xyz, dense_xyz_norm, nei_inds, ctr_xyz, ctr_norm,
-                                  vi_features)
+                                  vi_features, want_rel=False)
         guidance_x = self.guidance_unary(feats_x)
         chain = self._chain_layers(wn_in, nei_inds) if not strided else None
         if chain is not None:
