@@ -257,21 +257,25 @@ int pcf_hip_guidance_diff_backward(const float* ds, const int64_t* idx, const ui
  * stats [12][64] floats on the device: mean of layer l at stats + 64*l, 1/sqrt(var+eps) at stats + 64*(6+l).
  * forward, batch_stats != 0: statistics are computed (four recompute passes), written to stats and folded into
  * the running statistics (nullable); batch_stats == 0: the caller provides them and only score / w are produced.
- * pe, a1, h1, a2 (nullable) receive the intermediate activations [E, g], [E, 8], [E, 8], [E, 8]. */
+ * pe, a1, h1, a2 (nullable) receive the intermediate activations [E, g], [E, 8], [E, 8], [E, 8] (for the
+ * layer-at-a-time backward); h1_acc, a2_acc (nullable) the raw 8-channel accumulators of g1 and w2 (pre-BatchNorm,
+ * bias not added; for pcf_hip_pcf_chain_backward). */
 size_t pcf_hip_pcf_chain_workspace_bytes(void);
 int pcf_hip_pcf_chain_forward(const float* vi, const int64_t* idx, const float* u, long long E, long long rows_per_batch,
                               int N, int K, int cv, int g, int heads, int cm, const float* const* W,
                               const float* const* b, const float* const* gamma, const float* const* beta,
                               float* const* running_mean, float* const* running_var, float eps, float momentum,
-                              int batch_stats, float* stats, float* pe, float* a1, float* h1, float* a2, float* score,
-                              float* w, void* workspace, size_t workspace_bytes, void* stream);
-/* Adjoint of the training-mode forward given dscore [E, heads], dw [E, cm] (from pcf_hip_pcf_backward) and the
- * stats of the forward: du [B*N, 8] (zeroed here, float atomics) and, per layer, dW, db, dgamma, dbeta.
- * Nothing per-edge is read but vi / idx / dscore / dw: the chain is recomputed in each of four passes.  db is
- * written as zeros (a bias in front of a training-mode BatchNorm has an identically zero gradient). */
+                              int batch_stats, float* stats, float* pe, float* a1, float* h1, float* a2, float* h1_acc,
+                              float* a2_acc, float* score, float* w, void* workspace, size_t workspace_bytes,
+                              void* stream);
+/* Adjoint of the training-mode forward given dscore [E, heads], dw [E, cm] (from pcf_hip_pcf_backward), the
+ * stats and the h1_acc / a2_acc of the forward: du [B*N, 8] (zeroed here, float atomics) and, per layer, dW, db,
+ * dgamma, dbeta.  Four passes; the top layers are recomputed from the two stored accumulators, the first layers
+ * from vi; nothing per-edge is written.  db is written as zeros (a bias in front of a training-mode BatchNorm has
+ * an identically zero gradient). */
 size_t pcf_hip_pcf_chain_backward_workspace_bytes(void);
-int pcf_hip_pcf_chain_backward(const float* vi, const int64_t* idx, const float* u, const float* dscore, const float* dw,
-                               long long E, long long rows_per_batch, int N, int K, int cv, int g, int heads, int cm,
+int pcf_hip_pcf_chain_backward(const float* vi, const int64_t* idx, const float* h1_acc, const float* a2_acc,
+                               const float* dscore, const float* dw, long long E, long long rows_per_batch, int N, int K, int cv, int g, int heads, int cm,
                                const float* const* W, const float* const* b, const float* const* gamma,
                                const float* const* beta, const float* stats, float* du, float* const* dW,
                                float* const* db, float* const* dgamma, float* const* dbeta, void* workspace,

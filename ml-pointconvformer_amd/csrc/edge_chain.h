@@ -25,6 +25,7 @@ struct ChainArgs {
     const float* mean[6];       // device [64] each; filled pass by pass
     const float* rstd[6];
     float* pe; float* a1; float* h1; float* a2; float* score; float* w;
+    float* h1_acc; float* a2_acc;   // [E, 8] raw accumulators (pre-BatchNorm, bias not added) of g1 and w2, for the fused backward
     float* part;                // [blocks][2][64] partial sums of the pass
     int vec_vi;
 };

@@ -182,6 +182,10 @@ __global__ __launch_bounds__(BLOCK) void pcf_chain_kernel(const ChainArgs a) {
             x = x_next; x_next = x_nn; ucur = u_next; j_next = j_nn;
             continue;
         }
+        if (LEVEL == 3 && g < 2) {
+            if (a.h1_acc) st4(a.h1_acc + (size_t)e * CH + 4 * g, make_float4(h1[0], h1[1], h1[2], h1[3]));
+            if (a.a2_acc) st4(a.a2_acc + (size_t)e * CH + 4 * g, make_float4(a2[0], a2[1], a2[2], a2[3]));
+        }
         h1 = bn_relu(h1, cf[3], g);
         a2 = bn_relu(a2, cf[4], g);
         if (LEVEL == 3 && g < 2) {
@@ -304,8 +308,8 @@ int pcf_hip_pcf_chain_forward(const float* vi, const int64_t* idx, const float* 
                               int N, int K, int cv, int g, int heads, int cm, const float* const* W, const float* const* b,
                               const float* const* gamma, const float* const* beta, float* const* running_mean,
                               float* const* running_var, float eps, float momentum, int batch_stats, float* stats,
-                              float* pe, float* a1, float* h1, float* a2, float* score, float* w, void* workspace,
-                              size_t workspace_bytes, void* stream) {
+                              float* pe, float* a1, float* h1, float* a2, float* h1_acc, float* a2_acc, float* score,
+                              float* w, void* workspace, size_t workspace_bytes, void* stream) {
     using namespace pcf;
     PCF_REQUIRE(E >= 0 && rows_per_batch > 0 && N >= 0, "pcf_chain: bad sizes");
     if (cv < 1 || cv > CV || g < 1 || g > CG || heads < 1 || heads > CHD || cm < 1 || cm > CMX)
@@ -315,7 +319,7 @@ int pcf_hip_pcf_chain_forward(const float* vi, const int64_t* idx, const float* 
     if (E == 0) return ok();
     PCF_REQUIRE(vi && idx && u && W && b && gamma && beta && stats && score && w, "pcf_chain: null pointer");
     PCF_REQUIRE(aligned16(score) && aligned16(w) && aligned16(pe) && aligned16(a1) && aligned16(h1) && aligned16(a2) &&
-                    aligned16(u), "pcf_chain: buffers must be 16-byte aligned");       // null activation pointers: not written
+                    aligned16(u) && aligned16(h1_acc) && aligned16(a2_acc), "pcf_chain: buffers must be 16-byte aligned");       // null activation pointers: not written
     PCF_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= pcf_hip_pcf_chain_workspace_bytes(),
                 "pcf_chain: workspace too small or misaligned");
     hipStream_t s = (hipStream_t)stream;
@@ -328,6 +332,7 @@ int pcf_hip_pcf_chain_forward(const float* vi, const int64_t* idx, const float* 
         a.mean[l] = stats + l * 64; a.rstd[l] = stats + (6 + l) * 64;
     }
     a.pe = pe; a.a1 = a1; a.h1 = h1; a.a2 = a2; a.score = score; a.w = w;
+    a.h1_acc = h1_acc; a.a2_acc = a2_acc;
     a.part = static_cast<float*>(workspace);
     a.vec_vi = (cv % 4 == 0) && aligned16(vi);
     if (batch_stats) {

@@ -5,15 +5,19 @@
 //     dz = gamma * rstd * (g - mean(g) - xhat * mean(g * xhat)),    dbeta = sum g,   dgamma = sum g * xhat
 // so layer l's dz needs two global sums that depend on the dz of the layer above it -- three dependent
 // reductions down each branch.  Layer-at-a-time execution (edge_mlp_mfma.hip) reads and writes every
-// [E, 8..32] activation and gradient twice per layer (~2 kB per edge).  Here nothing but the layer-graph inputs
-// is read: each of four passes RECOMPUTES the forward chain from the 48-byte VI row (as edge_chain.hip does) and
-// walks the gradient down to the first layer whose sums are still unknown:
-//     pass 1: sums of g2 and w3                                  (reads VI, idx/u, dscore, dw)
+// [E, 8..32] activation and gradient twice per layer (~2 kB per edge).  Here each of four passes recomputes what
+// it needs and walks the gradient down to the first layer whose sums are still unknown.  The forward keeps ONE
+// thing per branch: the raw 8-channel accumulator of the middle layer (g1 / w2: 2 x 32 B per edge, written by
+// pass 3 of edge_chain.hip).  From it the top layer (g2 / w3) is one 8-wide product away, so passes 1 and 2 never
+// touch VI, the gathered term or the key subtraction; the first layers (mlp_conv / w1) are recomputed from the
+// 48-byte VI row only where their masks and inputs are needed (passes 3 and 4):
+//     pass 1: sums of g2 and w3                                  (reads the two accumulators, dscore, dw)
 //     pass 2: dz of g2, w3 -> dh1, da2;  sums of g1 and w2
-//     pass 3: dz of g1, w2 -> dpe, da1;  sums of mlp_conv and w1
+//     pass 3: dz of g1, w2 -> dpe, da1;  sums of mlp_conv and w1 (+ VI)
 //     pass 4: every dz; the six dW (outer products on the matrix cores, operands transposed through LDS) and
-//             the gradient of the gathered term u (row-contiguous float atomics)
-// 4 x ~176 B read per edge and no per-edge write at all.  Bias gradients of a Linear that feeds a training-mode
+//             the gradient of the gathered term u (row-contiguous float atomics; + the neighbour table)
+// 136 matrix instructions per 16 edges over the four passes instead of 208 with a full recompute, 160-220 B read
+// per edge and pass, no per-edge write at all.  Bias gradients of a Linear that feeds a training-mode
 // BatchNorm are identically zero (the mean subtraction cancels them) and are written as zeros.
 //
 // Matrix-core formulation as in edge_chain.hip (transposed, 16 edges per tile, lane (p = l & 15, g = l >> 4)
@@ -42,6 +46,8 @@ struct ChainBwdArgs {
     ChainArgs f;                // forward description (activation pointers unused)
     const float* dscore;        // [E, heads]
     const float* dw;            // [E, cm]
+    const float* h1_acc;        // [E, 8] raw accumulator of g1 (after the key subtraction, bias not added)
+    const float* a2_acc;        // [E, 8] raw accumulator of w2
     const float* gmean[6];      // mean over edges of g          (device [64] per layer, filled pass by pass)
     const float* gxmean[6];     // mean over edges of g * xhat
     float* du;                  // [B*N, 8], zeroed by the host; float atomics
@@ -196,45 +202,33 @@ __device__ __forceinline__ void guidance_branch(const ChainBwdArgs& a, const flo
     const TileIO io{a, p, g, ntiles};
     f32x4 s1[2] = {zero4, zero4}, s2[2] = {zero4, zero4};
     f32x4 accw[5] = {zero4, zero4, zero4, zero4, zero4};          // pe lo, pe hi, g1 (in lo), g1 (in hi), g2
-    const int lead = (lane & ~15) | (p & ~(f.K - 1));
     const bool first = (p & (f.K - 1)) == 0;
     BatchWalk walk;
     walk.init(f.rows_per_batch);
-    auto load_j = [&](long long tt) -> long long {               // called with increasing tt only
-        if (tt >= ntiles) return -1;
+    auto load_j = [&](long long tt) -> long long {               // called with increasing tt only; LEVEL 4 (du rows)
         const int batch = walk.batch_of(tt * 16, p);
         const int64_t j = f.idx[tt * 16 + p];
         return (j >= 0 && j < f.N) ? (long long)batch * f.N + j : -1;
     };
-    auto load_u = [&](long long row) -> f32x4 {
-        return (row >= 0 && g < 2) ? to_v4(ld4(f.u + (size_t)row * CH + 4 * g)) : zero4;
-    };
-    long long t = t0;
-    f32x4 x = io.load_x(t);
-    long long j_cur = load_j(t);
-    f32x4 ucur = load_u(j_cur);
-    long long j_next = load_j(t + tstride);
-    for (; t < ntiles; t += tstride) {
+    for (long long t = t0; t < ntiles; t += tstride) {
         asm volatile("" ::: "memory");          // LDS-resident weights / constants are re-read per tile, not hoisted into VGPRs
-        const f32x4 u_next = load_u(j_next);                      // gather of tile t+1, index of tile t+2, input of tile t+1
-        const long long j_nn = load_j(t + 2 * tstride);
-        const f32x4 x_next = io.load_x(t + tstride);
+        const f32x4 ac_h1 = io.load_grad(a.h1_acc, t, CH);
         const f32x4 dsc = io.load_grad(a.dscore, t, f.heads);
+        const f32x4 x = LEVEL >= 3 ? io.load_x(t) : zero4;
+        const long long j_cur = LEVEL == 4 ? load_j(t) : -1;
 
-        // ---- forward, keeping the raw accumulator (ac_*) of every layer ----
-        const f32x4 ac_pe0 = mm(wl, 0, lane, x, zero4);
-        const f32x4 ac_pe1 = mm(wl, 1, lane, x, zero4);
-        const f32x4 y_pe0 = relu4(pre_of(ac_pe0, cf[S_PE0], g));
-        const f32x4 y_pe1 = relu4(pre_of(ac_pe1, cf[S_PE1], g));
-        f32x4 h1 = mm(wl, 3, lane, y_pe0, zero4);
-        const f32x4 h1b = mm(wl, 4, lane, y_pe1, zero4);
-        h1 = h1 + h1b + ucur;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) h1[r] -= __shfl(h1[r], lead, WAVE);
-        const f32x4 ac_h1 = h1;
+        // ---- forward from the stored accumulator of g1: y_h1, then g2; the positional encoding only where its
+        //      mask / values are needed ----
         const f32x4 y_h1 = relu4(pre_of(ac_h1, cf[S_G1], g));
         const f32x4 ac_sc = mm(wl, 6, lane, y_h1, zero4);
         const f32x4 pre_sc = pre_of(ac_sc, cf[S_G2], g);
+        f32x4 ac_pe0 = zero4, ac_pe1 = zero4, y_pe0 = zero4, y_pe1 = zero4;
+        if (LEVEL >= 3) {
+            ac_pe0 = mm(wl, 0, lane, x, zero4);
+            ac_pe1 = mm(wl, 1, lane, x, zero4);
+            y_pe0 = relu4(pre_of(ac_pe0, cf[S_PE0], g));
+            y_pe1 = relu4(pre_of(ac_pe1, cf[S_PE1], g));
+        }
 
         // ---- backward ----
         f32x4 g_sc;
@@ -292,7 +286,6 @@ __device__ __forceinline__ void guidance_branch(const ChainBwdArgs& a, const flo
                 }
             }
         }
-        x = x_next; ucur = u_next; j_cur = j_next; j_next = j_nn;
     }
     if (LEVEL == 4) {
         const int tiles[5] = {0, 1, 3, 4, 6};
@@ -332,17 +325,19 @@ __device__ __forceinline__ void weightnet_branch(const ChainBwdArgs& a, const fl
     const TileIO io{a, p, g, ntiles};
     f32x4 s1 = zero4, s2 = zero4;
     f32x4 accw[3] = {zero4, zero4, zero4};                        // w1, w2, w3
-    long long t = t0;
-    f32x4 x = io.load_x(t);
-    for (; t < ntiles; t += tstride) {
+    for (long long t = t0; t < ntiles; t += tstride) {
         asm volatile("" ::: "memory");
-        const f32x4 x_next = io.load_x(t + tstride);
+        const f32x4 ac_a2 = io.load_grad(a.a2_acc, t, CH);
         const f32x4 dwv = io.load_grad(a.dw, t, f.cm);
-        const f32x4 ac_a1 = mm(wl, 2, lane, x, zero4);
-        const f32x4 y_a1 = relu4(pre_of(ac_a1, cf[S_W1], g));
-        const f32x4 ac_a2 = mm(wl, 5, lane, y_a1, zero4);
+        const f32x4 x = LEVEL >= 3 ? io.load_x(t) : zero4;
+        // forward from the stored accumulator of w2; w1 only where its mask / values are needed
         const f32x4 y_a2 = relu4(pre_of(ac_a2, cf[S_W2], g));
         const f32x4 ac_w = mm(wl, 7, lane, y_a2, zero4);
+        f32x4 ac_a1 = zero4, y_a1 = zero4;
+        if (LEVEL >= 3) {
+            ac_a1 = mm(wl, 2, lane, x, zero4);
+            y_a1 = relu4(pre_of(ac_a1, cf[S_W1], g));
+        }
         const f32x4 g_w = mask_pos(dwv, pre_of(ac_w, cf[S_W3], g));
         if (LEVEL == 1) {
             s1 += g_w; s2 += g_w * ac_w;
@@ -373,7 +368,6 @@ __device__ __forceinline__ void weightnet_branch(const ChainBwdArgs& a, const fl
                 }
             }
         }
-        x = x_next;
     }
     if (LEVEL == 4) {
         const int tiles[3] = {2, 5, 7};
@@ -545,8 +539,8 @@ size_t pcf_hip_pcf_chain_backward_workspace_bytes(void) {
     return ((size_t)1024 * pcf::NDW * 256 + 12 * 64) * 4 + 1024;
 }
 
-int pcf_hip_pcf_chain_backward(const float* vi, const int64_t* idx, const float* u, const float* dscore, const float* dw,
-                               long long E, long long rows_per_batch, int N, int K, int cv, int g, int heads, int cm,
+int pcf_hip_pcf_chain_backward(const float* vi, const int64_t* idx, const float* h1_acc, const float* a2_acc,
+                               const float* dscore, const float* dw, long long E, long long rows_per_batch, int N, int K, int cv, int g, int heads, int cm,
                                const float* const* W, const float* const* b, const float* const* gamma,
                                const float* const* beta, const float* stats, float* du, float* const* dW, float* const* db,
                                float* const* dgamma, float* const* dbeta, void* workspace, size_t workspace_bytes,
@@ -575,13 +569,14 @@ int pcf_hip_pcf_chain_backward(const float* vi, const int64_t* idx, const float*
     if (batches * N > 0 && hipMemsetAsync(du, 0, (size_t)batches * N * CH * 4, s) != hipSuccess)
         return fail(PCF_E_LAUNCH, "pcf_chain_backward: memset");
     if (E == 0) return ok();
-    PCF_REQUIRE(vi && idx && u && dscore && dw, "pcf_chain_backward: null pointer");
-    PCF_REQUIRE(aligned16(u) && aligned16(dscore) && aligned16(dw) && aligned16(du), "pcf_chain_backward: buffers must be 16-byte aligned");
+    PCF_REQUIRE(vi && idx && h1_acc && a2_acc && dscore && dw, "pcf_chain_backward: null pointer");
+    PCF_REQUIRE(aligned16(h1_acc) && aligned16(a2_acc) && aligned16(dscore) && aligned16(dw) && aligned16(du),
+                "pcf_chain_backward: buffers must be 16-byte aligned");
     PCF_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= pcf_hip_pcf_chain_backward_workspace_bytes(),
                 "pcf_chain_backward: workspace too small or misaligned");
     PCF_REQUIRE(batches * N < (1ll << 31), "pcf_chain_backward: too many points");
     ChainBwdArgs a{};
-    a.f.vi = vi; a.f.idx = idx; a.f.u = u; a.f.E = E; a.f.rows_per_batch = rows_per_batch; a.f.N = N; a.f.K = K;
+    a.f.vi = vi; a.f.idx = idx; a.f.u = nullptr; a.f.E = E; a.f.rows_per_batch = rows_per_batch; a.f.N = N; a.f.K = K;
     a.f.cv = cv; a.f.g = g; a.f.heads = heads; a.f.cm = cm;
     a.f.vec_vi = (cv % 4 == 0) && aligned16(vi);
     float* means = static_cast<float*>(workspace);           // [12][64]: mean g, then mean g*xhat, per layer
@@ -591,7 +586,7 @@ int pcf_hip_pcf_chain_backward(const float* vi, const int64_t* idx, const float*
         a.f.mean[l] = stats + l * 64; a.f.rstd[l] = stats + (6 + l) * 64;
         a.gmean[l] = means + l * 64; a.gxmean[l] = means + (6 + l) * 64;
     }
-    a.dscore = dscore; a.dw = dw; a.du = du;
+    a.dscore = dscore; a.dw = dw; a.du = du; a.h1_acc = h1_acc; a.a2_acc = a2_acc;
     // both branches need at least one workgroup; a multiple of 8 keeps the 5 : 3 split exact
     const int grid = std::max(8, (chain_grid(E) + 7) / 8 * 8);
     for (int pass = 0; pass < 3; ++pass) {

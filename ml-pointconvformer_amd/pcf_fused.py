@@ -391,14 +391,14 @@ _chain_ws.argtypes = []
 _chain_ws.restype = _Z
 _chain_fwd = _sig('pcf_hip_pcf_chain_forward',
                   [_P, _P, _P, _LL, _LL, _I, _I, _I, _I, _I, _I, _PP, _PP, _PP, _PP, _PP, _PP, _F, _F, _I, _P,
-                   _P, _P, _P, _P, _P, _P, _P, _Z, _P])
+                   _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P])
 
 
 _chain_bwd_ws = getattr(_lib, 'pcf_hip_pcf_chain_backward_workspace_bytes')
 _chain_bwd_ws.argtypes = []
 _chain_bwd_ws.restype = _Z
 _chain_bwd = _sig('pcf_hip_pcf_chain_backward',
-                  [_P, _P, _P, _P, _P, _LL, _LL, _I, _I, _I, _I, _I, _I, _PP, _PP, _PP, _PP, _P, _P, _PP, _PP, _PP, _PP,
+                  [_P, _P, _P, _P, _P, _P, _LL, _LL, _I, _I, _I, _I, _I, _I, _PP, _PP, _PP, _PP, _P, _P, _PP, _PP, _PP, _PP,
                    _P, _Z, _P])
 
 
@@ -452,9 +452,11 @@ class _PCFChain(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         score = torch.empty(B, M, K, heads, **f32)
         w = torch.empty(B, M, K, cm, **f32)
-        pe = a1 = h1 = a2 = None
+        pe = a1 = h1 = a2 = h1_acc = a2_acc = None
         if training:
-            if not fused_backward:      # the layer-at-a-time backward reads the intermediate activations
+            if fused_backward:          # the four-pass backward restarts from the raw accumulators of g1 and w2
+                h1_acc, a2_acc = torch.empty(B, M, K, 8, **f32), torch.empty(B, M, K, 8, **f32)
+            else:                       # the layer-at-a-time backward reads the intermediate activations
                 pe, a1 = torch.empty(B, M, K, g, **f32), torch.empty(B, M, K, 8, **f32)
                 h1, a2 = torch.empty(B, M, K, 8, **f32), torch.empty(B, M, K, 8, **f32)
             for bn in bns:
@@ -470,17 +472,18 @@ class _PCFChain(torch.autograd.Function):
         with torch.cuda.device(dev):
             _call(_chain_fwd, _ptr(vi), _ptr(idx), _ptr(u), E, M * K, N, K, cv, g, heads, cm, _ptr_array(Ws), _ptr_array(bs),
                   _ptr_array(gammas), _ptr_array(betas), rm, rv, float(bns[0].eps), float(mom), 1 if training else 0,
-                  stats.data_ptr(), _ptr(pe), _ptr(a1), _ptr(h1), _ptr(a2), _ptr(score), _ptr(w), ws.data_ptr(), nbytes,
+                  stats.data_ptr(), _ptr(pe), _ptr(a1), _ptr(h1), _ptr(a2), _ptr(h1_acc), _ptr(a2_acc), _ptr(score), _ptr(w),
+                  ws.data_ptr(), nbytes,
                   _stream(dev))
         agg = pcf_cuda.pcf_forward(fx, idx, score, w)
-        ctx.save_for_backward(idx, vi, u, fx, stats, pe, a1, h1, a2, score, w, *keep)
+        ctx.save_for_backward(idx, vi, u, fx, stats, pe, a1, h1, a2, h1_acc, a2_acc, score, w, *keep)
         ctx.training = bool(training)
         ctx.fused_backward = bool(fused_backward)
         return agg
 
     @staticmethod
     def backward(ctx, dagg):
-        idx, vi, u, fx, stats, pe, a1, h1, a2, score, w, *keep = ctx.saved_tensors
+        idx, vi, u, fx, stats, pe, a1, h1, a2, h1_acc, a2_acc, score, w, *keep = ctx.saved_tensors
         if not ctx.training:
             raise RuntimeError('pcf_chain: backward needs the training-mode forward (batch statistics)')
         Ws, bs, gammas, betas = keep[0::4], keep[1::4], keep[2::4], keep[3::4]
@@ -495,7 +498,8 @@ class _PCFChain(torch.autograd.Function):
                 grads = [torch.empty_like(t) for t in keep]
                 nbytes = _chain_bwd_ws()
                 ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-                _call(_chain_bwd, _ptr(vi), _ptr(idx), _ptr(u), _ptr(dscore), _ptr(dw), B * M * K, M * K, u.shape[1], K, cv,
+                _call(_chain_bwd, _ptr(vi), _ptr(idx), _ptr(h1_acc), _ptr(a2_acc), _ptr(dscore), _ptr(dw), B * M * K, M * K,
+                      u.shape[1], K, cv,
                       Ws[0].shape[0], Ws[2].shape[0], Ws[5].shape[0], _ptr_array(Ws), _ptr_array(bs), _ptr_array(gammas),
                       _ptr_array(betas), stats.data_ptr(), _ptr(du), _ptr_array(grads[0::4]), _ptr_array(grads[1::4]),
                       _ptr_array(grads[2::4]), _ptr_array(grads[3::4]), ws.data_ptr(), nbytes, _stream(dev))
