@@ -394,7 +394,7 @@ __device__ __forceinline__ void weightnet_branch(const ChainBwdArgs& a, const fl
 }
 
 // workgroup b of the launch: branch and rank among the workgroups of its branch; NG of every 8 workgroups take
-// the guidance branch (PCF_CHAIN_BWD_SPLIT, chosen per pass by measurement)
+// the guidance branch (SplitOf, chosen by measurement)
 template <int NG> __device__ __host__ inline bool is_guidance_block(int b) { return (b & 7) < NG; }
 template <int NG> __device__ __host__ inline int branch_rank(int b) {
     return is_guidance_block<NG>(b) ? (b >> 3) * NG + (b & 7) : (b >> 3) * (8 - NG) + (b & 7) - NG;
@@ -402,13 +402,9 @@ template <int NG> __device__ __host__ inline int branch_rank(int b) {
 template <int NG> __host__ inline int branch_blocks(int grid, bool guidance) {       // grid is a multiple of 8
     return guidance ? (grid >> 3) * NG : (grid >> 3) * (8 - NG);
 }
-#ifndef PCF_SPLIT_L123
-#define PCF_SPLIT_L123 5
-#endif
-#ifndef PCF_SPLIT_L4
-#define PCF_SPLIT_L4 5
-#endif
-template <int LEVEL> struct SplitOf { static constexpr int NG = LEVEL == 4 ? PCF_SPLIT_L4 : PCF_SPLIT_L123; };
+// matrix instructions per tile, guidance : WeightNet = 4 : 4 (pass 1), 8 : 8 (pass 2), 24 : 16 (pass 3), 44 : 28 (pass 4);
+// measured: 5 of 8 is best for passes 3-4 (6: +15 %) and within noise of 4 of 8 for the memory-bound passes 1-2
+template <int LEVEL> struct SplitOf { static constexpr int NG = 5; };
 
 template <int LEVEL>
 __global__ __launch_bounds__(BLOCK) void pcf_chain_bwd_kernel(const ChainBwdArgs a, int grid8) {
