@@ -248,6 +248,59 @@ __global__ __launch_bounds__(BLOCK) void pcf_chain_kernel(const ChainArgs a) {
     }
 }
 
+// Last pass of the training forward when pass 3 kept the raw accumulators of g1 and w2: score and w are one
+// 8-wide product away from them, so VI, the gathered term and the first two layers of each branch are not
+// recomputed (8 matrix instructions per tile instead of 32; 64 B read + 96 B written per edge).
+__global__ __launch_bounds__(BLOCK) void pcf_chain_tail_kernel(const ChainArgs a) {
+    __shared__ __align__(16) float cf[7][2][16];
+    stage_frags(a, cf, 4);
+    __syncthreads();
+    const int lane = lane_id(), wave = wave_id();
+    const int p = lane & 15, g = lane >> 4;
+    f32x4 w_g2, w_w3;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        w_g2[s] = wfrag(a.W[L_G2], a.heads, CH, p, 4 * g + s);
+        w_w3[s] = wfrag(a.W[L_W3], a.cm, CH, p, 4 * g + s);
+    }
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const long long ntiles = a.E / 16;
+    for (long long t = (long long)blockIdx.x * NWAVE + wave; t < ntiles; t += (long long)gridDim.x * NWAVE) {
+        const long long e = t * 16 + p;
+        f32x4 h1 = zero4, a2 = zero4;
+        if (g < 2) {
+            const float4 v1 = ld4(a.h1_acc + (size_t)e * CH + 4 * g), v2 = ld4(a.a2_acc + (size_t)e * CH + 4 * g);
+            h1 = f32x4{v1.x, v1.y, v1.z, v1.w};
+            a2 = f32x4{v2.x, v2.y, v2.z, v2.w};
+        }
+        h1 = bn_relu(h1, cf[3], g);
+        a2 = bn_relu(a2, cf[4], g);
+        if (g >= 2) { h1 = zero4; a2 = zero4; }          // channels 8..15 do not exist (their constants are 1 / 0)
+        f32x4 sc = zero4, wv = zero4;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            sc = PCF_MFMA(w_g2[s], h1[s], sc);
+            wv = PCF_MFMA(w_w3[s], a2[s], wv);
+        }
+        sc = bn_only(sc, cf[5], g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sc[r] = 1.f / (1.f + __expf(-sc[r]));
+        wv = bn_relu(wv, cf[6], g);
+        float* qs = a.score + (size_t)e * a.heads;
+        float* qw = a.w + (size_t)e * a.cm;
+        if ((a.heads & 3) == 0) { if (4 * g < a.heads) st4(qs + 4 * g, make_float4(sc[0], sc[1], sc[2], sc[3])); }
+        else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (4 * g + r < a.heads) qs[4 * g + r] = sc[r];
+        }
+        if ((a.cm & 3) == 0) { if (4 * g < a.cm) st4(qw + 4 * g, make_float4(wv[0], wv[1], wv[2], wv[3])); }
+        else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (4 * g + r < a.cm) qw[4 * g + r] = wv[r];
+        }
+    }
+}
+
 // Statistics of one pass: up to three groups of 16 channels; each group belongs to a layer at a channel
 // offset.  One thread per (group, channel): fp64 sum over the workgroup partials.
 struct FinGroup { float* mean; float* rstd; float* running_mean; float* running_var; const float* bias; int chan0; int count; };
@@ -357,7 +410,13 @@ int pcf_hip_pcf_chain_forward(const float* vi, const int64_t* idx, const float* 
             if (int e = check_launch("pcf_chain finalize")) return e;
         }
     }
-    hipLaunchKernelGGL(pcf_chain_kernel<4>, dim3(chain_grid(E)), dim3(BLOCK), 0, s, a);
+    if (batch_stats && h1_acc && a2_acc) {
+        const long long tiles = E / 16;
+        const int grid = (int)std::max<long long>(1, std::min<long long>((tiles + NWAVE - 1) / NWAVE, 2048));
+        hipLaunchKernelGGL(pcf_chain_tail_kernel, dim3(grid), dim3(BLOCK), 0, s, a);
+    } else {
+        hipLaunchKernelGGL(pcf_chain_kernel<4>, dim3(chain_grid(E)), dim3(BLOCK), 0, s, a);
+    }
     return check_launch("pcf_chain final pass");
 }
 
