@@ -174,6 +174,11 @@ __global__ __launch_bounds__(BLOCK) void pcf_chain_kernel(const ChainArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) h1[r] -= __shfl(h1[r], lead, WAVE);
         if (LEVEL == 2) {
+            // the raw accumulators of g1 / w2: passes 3, 4 and the fused backward restart from them
+            if (g < 2) {
+                if (a.h1_acc) st4(a.h1_acc + (size_t)e * CH + 4 * g, make_float4(h1[0], h1[1], h1[2], h1[3]));
+                if (a.a2_acc) st4(a.a2_acc + (size_t)e * CH + 4 * g, make_float4(a2[0], a2[1], a2[2], a2[3]));
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 s1[0][r] += h1[r]; s2[0][r] += h1[r] * h1[r];
@@ -181,10 +186,6 @@ __global__ __launch_bounds__(BLOCK) void pcf_chain_kernel(const ChainArgs a) {
             }
             x = x_next; x_next = x_nn; ucur = u_next; j_next = j_nn;
             continue;
-        }
-        if (LEVEL == 3 && g < 2) {
-            if (a.h1_acc) st4(a.h1_acc + (size_t)e * CH + 4 * g, make_float4(h1[0], h1[1], h1[2], h1[3]));
-            if (a.a2_acc) st4(a.a2_acc + (size_t)e * CH + 4 * g, make_float4(a2[0], a2[1], a2[2], a2[3]));
         }
         h1 = bn_relu(h1, cf[3], g);
         a2 = bn_relu(a2, cf[4], g);
@@ -248,12 +249,17 @@ __global__ __launch_bounds__(BLOCK) void pcf_chain_kernel(const ChainArgs a) {
     }
 }
 
-// Last pass of the training forward when pass 3 kept the raw accumulators of g1 and w2: score and w are one
-// 8-wide product away from them, so VI, the gathered term and the first two layers of each branch are not
-// recomputed (8 matrix instructions per tile instead of 32; 64 B read + 96 B written per edge).
+// Passes 3 and 4 of the training forward when pass 2 kept the raw accumulators of g1 and w2: the top layers
+// (g2, w3) are one 8-wide product away from them, so VI, the gathered term and the first two layers of each branch
+// are not recomputed (8 matrix instructions per tile instead of 32).  STATS: batch statistics of the raw g2 / w3
+// accumulators (64 B read per edge); else score and w (64 B read + 96 B written).
+template <bool STATS>
 __global__ __launch_bounds__(BLOCK) void pcf_chain_tail_kernel(const ChainArgs a) {
     __shared__ __align__(16) float cf[7][2][16];
-    stage_frags(a, cf, 4);
+    __shared__ float red[NWAVE][3][2][16];
+    stage_frags(a, cf, STATS ? 3 : 4);
+    if (STATS)
+        for (int t = threadIdx.x; t < NWAVE * 96; t += BLOCK) (&red[0][0][0][0])[t] = 0.f;
     __syncthreads();
     const int lane = lane_id(), wave = wave_id();
     const int p = lane & 15, g = lane >> 4;
@@ -264,6 +270,7 @@ __global__ __launch_bounds__(BLOCK) void pcf_chain_tail_kernel(const ChainArgs a
         w_w3[s] = wfrag(a.W[L_W3], a.cm, CH, p, 4 * g + s);
     }
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 s1[2] = {zero4, zero4}, s2[2] = {zero4, zero4};
     const long long ntiles = a.E / 16;
     for (long long t = (long long)blockIdx.x * NWAVE + wave; t < ntiles; t += (long long)gridDim.x * NWAVE) {
         const long long e = t * 16 + p;
@@ -275,12 +282,17 @@ __global__ __launch_bounds__(BLOCK) void pcf_chain_tail_kernel(const ChainArgs a
         }
         h1 = bn_relu(h1, cf[3], g);
         a2 = bn_relu(a2, cf[4], g);
-        if (g >= 2) { h1 = zero4; a2 = zero4; }          // channels 8..15 do not exist (their constants are 1 / 0)
+        if (g >= 2) { h1 = zero4; a2 = zero4; }          // channels 8..15 do not exist
         f32x4 sc = zero4, wv = zero4;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             sc = PCF_MFMA(w_g2[s], h1[s], sc);
             wv = PCF_MFMA(w_w3[s], a2[s], wv);
+        }
+        if (STATS) {
+            s1[0] += sc; s2[0] += sc * sc;
+            s1[1] += wv; s2[1] += wv * wv;
+            continue;
         }
         sc = bn_only(sc, cf[5], g);
 #pragma unroll
@@ -298,6 +310,24 @@ __global__ __launch_bounds__(BLOCK) void pcf_chain_tail_kernel(const ChainArgs a
 #pragma unroll
             for (int r = 0; r < 4; ++r) if (4 * g + r < a.cm) qw[4 * g + r] = wv[r];
         }
+    }
+    if (!STATS) return;
+#pragma unroll
+    for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v1 = s1[gi][r], v2 = s2[gi][r];
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) { v1 += __shfl_xor(v1, off, WAVE); v2 += __shfl_xor(v2, off, WAVE); }
+            if (p == 0) { red[wave][gi][0][4 * g + r] = v1; red[wave][gi][1][4 * g + r] = v2; }
+        }
+    __syncthreads();
+    if (threadIdx.x < 96) {
+        const int gi = threadIdx.x / 32, which = (threadIdx.x >> 4) & 1, c = threadIdx.x & 15;
+        float tsum = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWAVE; ++w) tsum += red[w][gi][which][c];
+        a.part[(size_t)blockIdx.x * 96 + threadIdx.x] = tsum;
     }
 }
 
@@ -388,11 +418,14 @@ int pcf_hip_pcf_chain_forward(const float* vi, const int64_t* idx, const float* 
     a.h1_acc = h1_acc; a.a2_acc = a2_acc;
     a.part = static_cast<float*>(workspace);
     a.vec_vi = (cv % 4 == 0) && aligned16(vi);
+    // passes 3 and 4 restart from the accumulators pass 2 stores, unless the caller wants h1 / a2 themselves
+    const bool from_acc = h1_acc && a2_acc && !h1 && !a2;
     if (batch_stats) {
         for (int pass = 0; pass < 3; ++pass) {
             int grid;
             if (pass == 0) { grid = chain_grid(E); hipLaunchKernelGGL(pcf_chain_kernel<1>, dim3(grid), dim3(BLOCK), 0, s, a); }
             else if (pass == 1) { grid = chain_grid(E); hipLaunchKernelGGL(pcf_chain_kernel<2>, dim3(grid), dim3(BLOCK), 0, s, a); }
+            else if (from_acc) { grid = chain_grid(E); hipLaunchKernelGGL(pcf_chain_tail_kernel<true>, dim3(grid), dim3(BLOCK), 0, s, a); }
             else { grid = chain_grid(E); hipLaunchKernelGGL(pcf_chain_kernel<3>, dim3(grid), dim3(BLOCK), 0, s, a); }
             if (int e = check_launch("pcf_chain pass")) return e;
             FinArgs f{};
@@ -410,10 +443,10 @@ int pcf_hip_pcf_chain_forward(const float* vi, const int64_t* idx, const float* 
             if (int e = check_launch("pcf_chain finalize")) return e;
         }
     }
-    if (batch_stats && h1_acc && a2_acc) {
+    if (batch_stats && from_acc) {
         const long long tiles = E / 16;
         const int grid = (int)std::max<long long>(1, std::min<long long>((tiles + NWAVE - 1) / NWAVE, 2048));
-        hipLaunchKernelGGL(pcf_chain_tail_kernel, dim3(grid), dim3(BLOCK), 0, s, a);
+        hipLaunchKernelGGL(pcf_chain_tail_kernel<false>, dim3(grid), dim3(BLOCK), 0, s, a);
     } else {
         hipLaunchKernelGGL(pcf_chain_kernel<4>, dim3(chain_grid(E)), dim3(BLOCK), 0, s, a);
     }
