@@ -39,7 +39,8 @@ __global__ __launch_bounds__(BLOCK) void col_partials_kernel(const float* __rest
                                                              long long R, int C, int TX, long long rows_per_block,
                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                             int act, float* __restrict__ part) {
+                                                             int act, float* __restrict__ part,
+                                                             const float* __restrict__ res = nullptr) {
     __shared__ float s1[BLOCK], s2[BLOCK];
     const int TY = BLOCK / TX;
     const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(BLOCK) void col_partials_kernel(const float* __rest
                 if (MODE == 0) { sa += v; sb += v * v; }
                 else {
                     const float xh = (v - mu) * rs;
-                    const float g = dy[(size_t)r * C + c] * bn_act_bwd(act, mean ? xh * ga + be : v);
+                    const float g = dy[(size_t)r * C + c] * bn_act_bwd(act, (mean ? xh * ga + be : v) + (res ? res[(size_t)r * C + c] : 0.f));
                     sa += g; sb += g * xh;
                 }
             };
@@ -148,7 +149,7 @@ __device__ __forceinline__ void load_col4(Col4& k, int c, const float* mean, con
 __global__ __launch_bounds__(BLOCK) void bnact_fwd_kernel(const float* __restrict__ z, float* __restrict__ y, long long total,
                                                           int C, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                          int act, int vec, int fixed_cols) {
+                                                          int act, int vec, int fixed_cols, const float* __restrict__ res) {
     if (vec) {
         const long long units = total >> 2;
         const long long u0 = (long long)blockIdx.x * BLOCK + threadIdx.x;
@@ -157,12 +158,15 @@ __global__ __launch_bounds__(BLOCK) void bnact_fwd_kernel(const float* __restric
         for (long long u = u0; u < units; u += (long long)gridDim.x * BLOCK) {
             if (mean && !fixed_cols) load_col4(k, (int)((u * 4) % C), mean, rstd, gamma, beta);
             float4 v = ld4(z + u * 4);
+            float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (res) rv = ld4(res + u * 4);
             float* e = &v.x;
+            const float* re = &rv.x;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float t = e[j];
                 if (mean) t = (t - k.mu[j]) * k.rs[j] * k.ga[j] + k.be[j];
-                e[j] = bn_act_fwd(act, t);
+                e[j] = bn_act_fwd(act, t + re[j]);
             }
             st4(y + u * 4, v);
         }
@@ -171,7 +175,7 @@ __global__ __launch_bounds__(BLOCK) void bnact_fwd_kernel(const float* __restric
             const int c = (int)(i % C);
             float t = z[i];
             if (mean) t = (t - mean[c]) * rstd[c] * gamma[c] + beta[c];
-            y[i] = bn_act_fwd(act, t);
+            y[i] = bn_act_fwd(act, t + (res ? res[i] : 0.f));
         }
     }
 }
@@ -180,17 +184,22 @@ __global__ __launch_bounds__(BLOCK) void bnact_bwd_kernel(const float* __restric
                                                           float* __restrict__ dz, long long total, int C,
                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                          const float* __restrict__ m1, const float* __restrict__ m2, int act) {
+                                                          const float* __restrict__ m1, const float* __restrict__ m2, int act,
+                                                          const float* __restrict__ res, float* __restrict__ dres) {
     // one element per lane and round: a float4 form of this kernel measured ~2x slower on gfx950 (31 vs 13 us at [80k, 64])
     for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < total; i += (long long)gridDim.x * BLOCK) {
         const int c = (int)(i % C);
         const float v = z[i];
+        const float rsd = res ? res[i] : 0.f;
         if (mean) {
             const float xh = (v - mean[c]) * rstd[c];
-            const float g = dy[i] * bn_act_bwd(act, xh * gamma[c] + beta[c]);
+            const float g = dy[i] * bn_act_bwd(act, xh * gamma[c] + beta[c] + rsd);
+            if (dres) dres[i] = g;
             dz[i] = rstd[c] * gamma[c] * (m1 ? (g - m1[c] - xh * m2[c]) : g);
         } else {
-            dz[i] = dy[i] * bn_act_bwd(act, v);
+            const float g = dy[i] * bn_act_bwd(act, v + rsd);
+            if (dres) dres[i] = g;
+            dz[i] = g;
         }
     }
 }
@@ -233,22 +242,35 @@ int pcf_hip_bnact_stats(const float* z, long long R, int C, float eps, float mom
     return check_launch("bnact statistics");
 }
 
-int pcf_hip_bnact_forward(const float* z, long long R, int C, const float* mean, const float* rstd, const float* gamma,
-                          const float* beta, int act, float* y, void* stream) {
+int pcf_hip_bnact_forward_res(const float* z, const float* residual, long long R, int C, const float* mean,
+                              const float* rstd, const float* gamma, const float* beta, int act, float* y, void* stream) {
     using namespace pcf;
     PCF_REQUIRE(R >= 0 && C >= 1 && act >= 0 && act <= 3, "bnact_forward: bad arguments");
     if (R == 0) return ok();
     PCF_REQUIRE(z && y && (!mean || (rstd && gamma && beta)), "bnact_forward: null pointer");
     const long long total = R * C;
-    const int vec = (C % 4 == 0) && aligned16(z) && aligned16(y);
+    const int vec = (C % 4 == 0) && aligned16(z) && aligned16(y) && aligned16(residual);
     hipLaunchKernelGGL(bnact_fwd_kernel, dim3(ew_grid(vec ? total / 4 : total)), dim3(BLOCK), 0, (hipStream_t)stream, z, y,
-                       total, C, mean, rstd, gamma, beta, act, vec, (4 * BLOCK) % C == 0);
+                       total, C, mean, rstd, gamma, beta, act, vec, (4 * BLOCK) % C == 0, residual);
     return check_launch("bnact forward");
+}
+
+int pcf_hip_bnact_forward(const float* z, long long R, int C, const float* mean, const float* rstd, const float* gamma,
+                          const float* beta, int act, float* y, void* stream) {
+    return pcf_hip_bnact_forward_res(z, nullptr, R, C, mean, rstd, gamma, beta, act, y, stream);
 }
 
 int pcf_hip_bnact_backward(const float* z, const float* dy, long long R, int C, const float* mean, const float* rstd,
                            const float* gamma, const float* beta, int batch_stats, int act, float* dz, float* dgamma,
                            float* dbeta, void* workspace, size_t workspace_bytes, void* stream) {
+    return pcf_hip_bnact_backward_res(z, nullptr, dy, R, C, mean, rstd, gamma, beta, batch_stats, act, dz, nullptr, dgamma,
+                                      dbeta, workspace, workspace_bytes, stream);
+}
+
+int pcf_hip_bnact_backward_res(const float* z, const float* residual, const float* dy, long long R, int C, const float* mean,
+                               const float* rstd, const float* gamma, const float* beta, int batch_stats, int act,
+                               float* dz, float* dresidual, float* dgamma, float* dbeta, void* workspace,
+                               size_t workspace_bytes, void* stream) {
     using namespace pcf;
     PCF_REQUIRE(R >= 0 && C >= 1 && act >= 0 && act <= 3, "bnact_backward: bad arguments");
     hipStream_t s = (hipStream_t)stream;
@@ -269,14 +291,14 @@ int pcf_hip_bnact_backward(const float* z, const float* dy, long long R, int C, 
         const int nb = stats_blocks(R);
         const long long rpb = (R + nb - 1) / nb;
         hipLaunchKernelGGL(col_partials_kernel<1>, dim3(nb), dim3(BLOCK), 0, s, z, dy, R, C, tx_for(C), rpb, mean, rstd, gamma,
-                           beta, act, part);
+                           beta, act, part, residual);
         hipLaunchKernelGGL(col_finalize_kernel<1>, dim3(ceil_div(C, FIN_COLS)), dim3(FIN_THREADS), 0, s, part, nb, R, C, 0.f, 0.f, nullptr,
                            nullptr, dbeta, dgamma, m1, m2);
         if (int e = check_launch("bnact backward reductions")) return e;
         if (!batch_stats) { m1 = nullptr; m2 = nullptr; }
     }
     hipLaunchKernelGGL(bnact_bwd_kernel, dim3(std::min(ew_grid(R * C), 4096)), dim3(BLOCK), 0, s, z, dy, dz, R * C, C, mean,
-                       rstd, gamma, beta, m1, m2, act);
+                       rstd, gamma, beta, m1, m2, act, residual, dresidual);
     return check_launch("bnact backward");
 }
 

@@ -295,8 +295,8 @@ _bnact_ws = getattr(_lib, 'pcf_hip_bnact_workspace_bytes')
 _bnact_ws.argtypes = [_LL, _I]
 _bnact_ws.restype = _Z
 _bnact_stats = _sig('pcf_hip_bnact_stats', [_P, _LL, _I, _F, _F, _P, _P, _P, _P, _P, _Z, _P])
-_bnact_fwd = _sig('pcf_hip_bnact_forward', [_P, _LL, _I, _P, _P, _P, _P, _I, _P, _P])
-_bnact_bwd = _sig('pcf_hip_bnact_backward', [_P, _P, _LL, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _Z, _P])
+_bnact_fwd = _sig('pcf_hip_bnact_forward_res', [_P, _P, _LL, _I, _P, _P, _P, _P, _I, _P, _P])
+_bnact_bwd = _sig('pcf_hip_bnact_backward_res', [_P, _P, _P, _LL, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _Z, _P])
 _linbwd_ws = getattr(_lib, 'pcf_hip_linear_backward_workspace_bytes')
 _linbwd_ws.argtypes = [_LL, _I, _I]
 _linbwd_ws.restype = _Z
@@ -305,8 +305,9 @@ _linbwd = _sig('pcf_hip_linear_backward', [_P, _P, _P, _LL, _I, _I, _P, _P, _P, 
 
 class _WideLinearBNAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, W, b, gamma, beta, running_mean, running_var, eps, momentum, training, act):
+    def forward(ctx, x, W, b, gamma, beta, running_mean, running_var, eps, momentum, training, act, residual=None):
         x, W, b = x.contiguous(), W.contiguous(), b.contiguous()
+        residual = residual.contiguous() if residual is not None else None
         Cout, Cin = W.shape
         R = x.numel() // Cin
         dev = x.device
@@ -325,21 +326,22 @@ class _WideLinearBNAct(torch.autograd.Function):
                       _ptr(mean), _ptr(rstd), ws.data_ptr(), nbytes, stream)
             elif bn:
                 mean, rstd = running_mean, torch.rsqrt(running_var + eps)
-            if bn or act != ACT_NONE:
+            if bn or act != ACT_NONE or residual is not None:
                 y = torch.empty_like(z)
-                _call(_bnact_fwd, _ptr(z), R, Cout, _ptr(mean), _ptr(rstd), _ptr(gamma) if bn else None,
+                _call(_bnact_fwd, _ptr(z), _ptr(residual), R, Cout, _ptr(mean), _ptr(rstd), _ptr(gamma) if bn else None,
                       _ptr(beta) if bn else None, int(act), _ptr(y), stream)
             else:
                 y = z
-        ctx.save_for_backward(x, W, z, gamma, beta, mean, rstd)
+        ctx.save_for_backward(x, W, z, gamma, beta, mean, rstd, residual)
         ctx.cfg = (bool(training), int(act), bn)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, W, z, gamma, beta, mean, rstd = ctx.saved_tensors
+        x, W, z, gamma, beta, mean, rstd, residual = ctx.saved_tensors
         training, act, bn = ctx.cfg
         dy = dy.contiguous()
+        dres = None
         Cout, Cin = W.shape
         R = x.numel() // Cin
         dev = x.device
@@ -349,37 +351,44 @@ class _WideLinearBNAct(torch.autograd.Function):
         with torch.cuda.device(dev):
             if bn or act != ACT_NONE:
                 dz = torch.empty_like(z)
+                if residual is not None and ctx.needs_input_grad[11]:
+                    dres = torch.empty_like(z)
                 nbytes = _bnact_ws(R, Cout)
                 ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-                _call(_bnact_bwd, _ptr(z), _ptr(dy), R, Cout, _ptr(mean), _ptr(rstd), _ptr(gamma) if bn else None,
-                      _ptr(beta) if bn else None, 1 if training else 0, act, _ptr(dz), _ptr(dgamma), _ptr(dbeta),
-                      ws.data_ptr(), nbytes, stream)
+                _call(_bnact_bwd, _ptr(z), _ptr(residual), _ptr(dy), R, Cout, _ptr(mean), _ptr(rstd),
+                      _ptr(gamma) if bn else None, _ptr(beta) if bn else None, 1 if training else 0, act, _ptr(dz),
+                      _ptr(dres), _ptr(dgamma), _ptr(dbeta), ws.data_ptr(), nbytes, stream)
             else:
                 dz = dy
+                dres = dy if residual is not None else None
             dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
             dW = torch.empty_like(W)
             db = torch.empty(Cout, dtype=torch.float32, device=dev)
             nbytes = _linbwd_ws(R, Cin, Cout)
             ws2 = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             _call(_linbwd, _ptr(dz), _ptr(x), _ptr(W), R, Cin, Cout, _ptr(dx), _ptr(dW), _ptr(db), ws2.data_ptr(), nbytes, stream)
-        return dx, dW, db, dgamma, dbeta, None, None, None, None, None, None
+        return dx, dW, db, dgamma, dbeta, None, None, None, None, None, None, dres
 
 
-def wide_linear_bn_act(x, weight, bias, bn, act, training):
-    """Linear (+BatchNorm1d module `bn` or None) (+activation) for channel counts beyond the per-edge
-    engine's 64: MFMA contraction + column-wise BN kernels, fully on HIP."""
+def wide_linear_bn_act(x, weight, bias, bn, act, training, residual=None):
+    """Linear (+BatchNorm1d module `bn` or None) (+residual) (+activation) for channel counts beyond the per-edge
+    engine's 64: MFMA contraction + column-wise BN kernels, fully on HIP.  y = act(BN(x W^T + b) + residual)."""
     x, weight, bias = x.contiguous(), weight.contiguous(), bias.contiguous()
     _floats(x=x, weight=weight, bias=bias)
+    if residual is not None:
+        _floats(residual=residual)
+        if tuple(residual.shape) != tuple(x.shape[:-1]) + (weight.shape[0],):
+            raise RuntimeError('wide_linear_bn_act: residual must have the shape of the output')
     if x.numel() // x.shape[-1] >= 2 ** 31:
         raise RuntimeError('wide_linear_bn_act: more than 2^31 rows')
     if bn is None:
-        return _WideLinearBNAct.apply(x, weight, bias, None, None, None, None, 0.0, 0.0, False, act)
+        return _WideLinearBNAct.apply(x, weight, bias, None, None, None, None, 0.0, 0.0, False, act, residual)
     use_batch = training or bn.running_mean is None
     if training and bn.num_batches_tracked is not None:
         bn.num_batches_tracked += 1
     momentum = 0.1 if bn.momentum is None else bn.momentum
     return _WideLinearBNAct.apply(x, weight, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, momentum,
-                                  use_batch, act)
+                                  use_batch, act, residual)
 
 
 # --------------------------------------------------------------------------------------------------

@@ -178,6 +178,12 @@ class Linear_BN(nn.Module):
         # wide point-level layers: fp32 MFMA contraction + column-wise BatchNorm kernels
         return pcf_fused.wide_linear_bn_act(x, self.c.weight, self.c.bias, self.bn, act, self.training)
 
+    def forward_residual(self, x, residual, act):
+        """act(BN(x W^T + b) + residual): in one kernel after the contraction on the wide path."""
+        if pcf_fused.rowlin_supported(self.c.in_features, self.c.out_features):
+            return _apply_act(self.forward(x) + residual, act)
+        return pcf_fused.wide_linear_bn_act(x, self.c.weight, self.c.bias, self.bn, act, self.training, residual=residual)
+
 
 def _apply_act(y, act):
     if act == pcf_fused.ACT_RELU:
@@ -207,6 +213,12 @@ class UnaryBlock(nn.Module):
 
     def forward(self, x):
         return _linear_act(self.mlp, x, pcf_fused.ACT_NONE if self.no_relu else pcf_fused.ACT_LEAKY)
+
+    def forward_residual(self, x, residual, act):
+        """act(block(x) + residual) for a block without its own activation (the tail of the residual layers)."""
+        if self.no_relu and isinstance(self.mlp, Linear_BN):
+            return self.mlp.forward_residual(x, residual, act)
+        return _apply_act(self.forward(x) + residual, act)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -365,10 +377,12 @@ class PCFLayer(nn.Module):
                 inv_neighbors = inv_k = inv_idx = None      # float atomics are ~25 % faster than the CSR reduce here
             agg = PCF.forward(feats_x.contiguous(), nei_inds, guidance_score.contiguous(), weights.contiguous(),
                               inv_neighbors, inv_k, inv_idx)
-        new_feat = self.unary2(self.dropout(_linear_act(self.linear, agg, pcf_fused.ACT_RELU)))
         sparse_feats = pcf_fused.gather_max(dense_feats, nei_inds) if strided else dense_feats
         shortcut = self.unary_shortcut(sparse_feats)
-        return F.leaky_relu(self.drop_path(new_feat) + shortcut, 0.1), wn_in
+        # leaky_relu(drop_path(unary2(.)) + shortcut): drop_path is the identity (rate 0 in every BASELINE config)
+        new_feat = self.unary2.forward_residual(self.dropout(_linear_act(self.linear, agg, pcf_fused.ACT_RELU)), shortcut,
+                                                pcf_fused.ACT_LEAKY)
+        return new_feat, wn_in
 
 
 class _ConvTail(nn.Module):
@@ -426,10 +440,9 @@ class PointConvStridePE(_ConvTail):
         feat_pe = self.pe_convs(rel)
         weights = self.weightnet(wn_in)
         y = F.relu(self._aggregate_linear(feats_x, nei_inds, weights, feat_pe, inv_neighbors, inv_k, inv_idx))
-        y = self.unary2(self.dropout(y))
         sparse_feats = pcf_fused.gather_max(dense_feats, nei_inds) if strided else dense_feats
         shortcut = self.unary_shortcut(sparse_feats)
-        return F.leaky_relu(self.drop_path(y) + shortcut, 0.1), wn_in
+        return self.unary2.forward_residual(self.dropout(y), shortcut, pcf_fused.ACT_LEAKY), wn_in
 
 
 class PointConv(_ConvTail):
