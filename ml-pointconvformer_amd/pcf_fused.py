@@ -468,9 +468,9 @@ class _PCFChain(torch.autograd.Function):
             else:                       # the layer-at-a-time backward reads the intermediate activations
                 pe, a1 = torch.empty(B, M, K, g, **f32), torch.empty(B, M, K, 8, **f32)
                 h1, a2 = torch.empty(B, M, K, 8, **f32), torch.empty(B, M, K, 8, **f32)
-            for bn in bns:
-                if bn.num_batches_tracked is not None:
-                    bn.num_batches_tracked += 1
+            tracked = [bn.num_batches_tracked for bn in bns if bn.num_batches_tracked is not None]
+            if tracked:
+                torch._foreach_add_(tracked, 1)            # one launch for the six counters
         nbytes = _chain_ws()
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         keep = [t.contiguous() for t in params]
@@ -529,13 +529,30 @@ class _PCFChain(torch.autograd.Function):
         return (None, None, None, None, None, du, dfx, *grads)
 
 
+class _SplitColumns(torch.autograd.Function):
+    """W [O, A+B] -> (W[:, :A], W[:, A:]) as contiguous tensors; the backward is one concatenation instead of two
+    zero-fill + copy + accumulate chains of the slicing ops."""
+
+    @staticmethod
+    def forward(ctx, W, A):
+        return W[:, :A].contiguous(), W[:, A:].contiguous()
+
+    @staticmethod
+    def backward(ctx, dA, dB):
+        return torch.cat([dA, dB], dim=1), None
+
+
+def split_columns(W, A):
+    return _SplitColumns.apply(W, A)
+
+
 def pcf_chain_supported(cv, g, heads, cm, K, hidden_ok, n_edges, edges_per_batch=16):
     """Shapes the fused MFMA chain covers: a neighbourhood must fit one 16-edge tile."""
     return hidden_ok and 1 <= cv <= 12 and 1 <= g <= 32 and 1 <= heads <= 8 and 1 <= cm <= 16 \
         and 1 <= K <= 16 and (K & (K - 1)) == 0 and n_edges % 16 == 0 and edges_per_batch >= 16
 
 
-def pcf_chain(vi, idx, u, fx, layers, training, fused_backward=True):
+def pcf_chain(vi, idx, u, fx, layers, training, fused_backward=True, g1_positional_weight=None):
     """layers: six (nn.Linear, nn.BatchNorm1d) pairs in the order mlp_conv, g1, g2, w1, w2, w3; the g1 weight is
     split here (its gathered half already went into `u`).  fused_backward: adjoint through the four-pass
     recompute kernel (csrc/edge_chain_bwd.hip); False keeps the activations and goes layer by layer."""
@@ -544,6 +561,8 @@ def pcf_chain(vi, idx, u, fx, layers, training, fused_backward=True):
     G = layers[0][0].out_features
     params = []
     for l, (lin, bn) in enumerate(layers):
-        W = lin.weight[:, lin.weight.shape[1] - G:] if l == 1 else lin.weight
+        W = lin.weight
+        if l == 1:      # positional half of the first guidance layer (the gathered half already went into `u`)
+            W = g1_positional_weight if g1_positional_weight is not None else lin.weight[:, lin.weight.shape[1] - G:]
         params += [W, lin.bias, bn.weight, bn.bias]
     return _PCFChain.apply(idx, [bn for _, bn in layers], training, fused_backward, vi, u, fx, *params)

@@ -312,6 +312,7 @@ class PCFLayer(nn.Module):
             raise NotImplementedError('QK guidance is outside the hot path (SURVEY.md 8f-4)')
         self.cfg, self.in_channel, self.out_channel, self.num_heads = cfg, in_channel, out_channel, num_heads
         self.drop_path = _drop_path(cfg)
+        self._zero8 = torch.zeros(8)        # bias of the per-point half of the first guidance layer (not a parameter / buffer)
         self.mlp_conv = Linear_BN(12, guidance_feat_len) if cfg.BATCH_NORM else nn.Linear(12, guidance_feat_len)
         mid = out_channel // 4
         self.unary1 = UnaryBlock(in_channel, mid, use_bn=True, bn_momentum=0.1) if in_channel != mid else nn.Identity()
@@ -358,10 +359,13 @@ class PCFLayer(nn.Module):
             # self neighbourhoods, BatchNorm everywhere: the whole edge graph in four fused passes
             g1 = self.guidance_weight.mlp[0].c
             G = guidance_x.shape[-1]
-            u = pcf_fused.linear_bn_act(guidance_x, g1.weight[:, :G], g1.weight.new_zeros(g1.out_features), None,
-                                        pcf_fused.ACT_NONE, self.training)
+            Wa, Wb = pcf_fused.split_columns(g1.weight, G)      # gathered half | positional half
+            if self._zero8.device != Wa.device:
+                self._zero8 = self._zero8.to(Wa.device)
+            u = pcf_fused.linear_bn_act(guidance_x, Wa, self._zero8[:g1.out_features], None, pcf_fused.ACT_NONE, self.training)
             agg = pcf_fused.pcf_chain(wn_in.contiguous(), nei_inds, u, feats_x.contiguous(), chain, self.training,
-                                      fused_backward=not getattr(self.cfg, 'EDGE_CHAIN_LAYERWISE_BACKWARD', False))
+                                      fused_backward=not getattr(self.cfg, 'EDGE_CHAIN_LAYERWISE_BACKWARD', False),
+                                      g1_positional_weight=Wb)
         else:
             feat_pe = _linear_act(self.mlp_conv, wn_in, pcf_fused.ACT_RELU)
             if not strided and pcf_fused.split_guidance_supported(nei_inds.shape[2], 8) \
