@@ -432,10 +432,10 @@ bool rowlin_mfma_supported(const RowLin& a) {
 // A wave keeps one 16-row tile of loads in flight, so the latency hiding comes from resident waves: up to 2048
 // workgroups.  Against that, every workgroup pays a fixed prologue and (backward) writes a Cout x 16*TI partial of
 // dW -- 16 KB at Cin = 64 -- so wide-input layers get TI tiles per wave: at R = 80k, Cin = 64 that is 313
-// workgroups (24 us) instead of 1250 (32 us), while the 8..16-wide per-edge layers keep one tile per wave.
+// workgroups (24 us) instead of 1250 (32 us); the 8..16-wide layers take two tiles per wave.
 int rowlin_mfma_grid(long long R, int Cin) {
     const long long tiles = (R + 15) / 16;
-    const long long per_wg = (long long)NWAVE * tiles_of(Cin);
+    const long long per_wg = (long long)NWAVE * std::max(tiles_of(Cin), 2);      // measured: 2 beats 1 and 4 for 16-wide inputs
     return (int)std::max<long long>(1, std::min<long long>((tiles + per_wg - 1) / per_wg, 2048));
 }
 
