@@ -281,7 +281,7 @@ int pcf_hip_pcf_chain_forward(const float* vi, const int64_t* idx, const float* 
  * dgamma, dbeta.  Four passes; the top layers are recomputed from the two stored accumulators, the first layers
  * from vi; nothing per-edge is written.  db is written as zeros (a bias in front of a training-mode BatchNorm has
  * an identically zero gradient). */
-size_t pcf_hip_pcf_chain_backward_workspace_bytes(void);
+size_t pcf_hip_pcf_chain_backward_workspace_bytes(long long E);
 int pcf_hip_pcf_chain_backward(const float* vi, const int64_t* idx, const float* h1_acc, const float* a2_acc,
                                const float* dscore, const float* dw, long long E, long long rows_per_batch, int N, int K, int cv, int g, int heads, int cm,
                                const float* const* W, const float* const* b, const float* const* gamma,

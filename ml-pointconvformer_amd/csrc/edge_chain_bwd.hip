@@ -12,12 +12,14 @@
 // touch VI, the gathered term or the key subtraction; the first layers (mlp_conv / w1) are recomputed from the
 // 48-byte VI row only where their masks and inputs are needed (passes 3 and 4):
 //     pass 1: sums of g2 and w3                                  (reads the two accumulators, dscore, dw)
-//     pass 2: dz of g2, w3 -> dh1, da2;  sums of g1 and w2
-//     pass 3: dz of g1, w2 -> dpe, da1;  sums of mlp_conv and w1 (+ VI)
-//     pass 4: every dz; the six dW (outer products on the matrix cores, operands transposed through LDS) and
-//             the gradient of the gathered term u (row-contiguous float atomics; + the neighbour table)
-// 136 matrix instructions per 16 edges over the four passes instead of 208 with a full recompute, 160-220 B read
-// per edge and pass, no per-edge write at all.  Bias gradients of a Linear that feeds a training-mode
+//     pass 2: dz of g2, w3 -> dW of g2, w3;  g = dh1, da2 masked by the ReLU of g1, w2 -> stored (2 x 32 B per
+//             edge) with their sums: the top layers are finished here and never touched again
+//     pass 3: dz of g1, w2 (from the stored g) -> dpe, da1;  sums of mlp_conv and w1 (+ VI)
+//     pass 4: dz of the four lower layers, their dW (outer products on the matrix cores, operands transposed
+//             through LDS) and the gradient of the gathered term u (row-contiguous float atomics; + the
+//             neighbour table)
+// 104 matrix instructions per 16 edges over the four passes instead of 208 with a full recompute; 160-180 B read
+// per edge and pass, 64 B written once.  Bias gradients of a Linear that feeds a training-mode
 // BatchNorm are identically zero (the mean subtraction cancels them) and are written as zeros.
 //
 // Matrix-core formulation as in edge_chain.hip (transposed, 16 edges per tile, lane (p = l & 15, g = l >> 4)
@@ -50,6 +52,9 @@ struct ChainBwdArgs {
     const float* a2_acc;        // [E, 8] raw accumulator of w2
     const float* gmean[6];      // mean over edges of g          (device [64] per layer, filled pass by pass)
     const float* gxmean[6];     // mean over edges of g * xhat
+    float* gh1;                 // [E, 8] dh1 * [h1 > 0], written by pass 2, read by passes 3-4 (workspace)
+    float* ga2;                 // [E, 8] da2 * [a2 > 0]
+    float* part_top;            // [blocks][2][256] dW tiles of g2 / w3 from pass 2
     float* du;                  // [B*N, 8], zeroed by the host; float atomics
     float* part;                // pass partials
 };
@@ -194,7 +199,8 @@ struct TileIO {
 //   red (LEVEL < 4): groups {L1: g2 | L2: g1 | L3: pe lo, pe hi};   LEVEL 4: dW tiles 0, 1, 3, 4, 6 and du.
 template <int LEVEL>
 __device__ __forceinline__ void guidance_branch(const ChainBwdArgs& a, const float (*cf)[NCONST][16], const float4* wl,
-                                                float* red, float* tb, int* gi, long long t0, long long tstride) {
+                                                float* red, float* red_top, float* tb, int* gi, long long t0,
+                                                long long tstride) {
     const ChainArgs& f = a.f;
     const int lane = lane_id(), wave = wave_id(), p = lane & 15, g = lane >> 4;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -213,92 +219,95 @@ __device__ __forceinline__ void guidance_branch(const ChainBwdArgs& a, const flo
     for (long long t = t0; t < ntiles; t += tstride) {
         asm volatile("" ::: "memory");          // LDS-resident weights / constants are re-read per tile, not hoisted into VGPRs
         const f32x4 ac_h1 = io.load_grad(a.h1_acc, t, CH);
-        const f32x4 dsc = io.load_grad(a.dscore, t, f.heads);
-        const f32x4 x = LEVEL >= 3 ? io.load_x(t) : zero4;
-        const long long j_cur = LEVEL == 4 ? load_j(t) : -1;
-
-        // ---- forward from the stored accumulator of g1: y_h1, then g2; the positional encoding only where its
-        //      mask / values are needed ----
-        const f32x4 y_h1 = relu4(pre_of(ac_h1, cf[S_G1], g));
-        const f32x4 ac_sc = mm(wl, 6, lane, y_h1, zero4);
-        const f32x4 pre_sc = pre_of(ac_sc, cf[S_G2], g);
-        f32x4 ac_pe0 = zero4, ac_pe1 = zero4, y_pe0 = zero4, y_pe1 = zero4;
-        if (LEVEL >= 3) {
-            ac_pe0 = mm(wl, 0, lane, x, zero4);
-            ac_pe1 = mm(wl, 1, lane, x, zero4);
-            y_pe0 = relu4(pre_of(ac_pe0, cf[S_PE0], g));
-            y_pe1 = relu4(pre_of(ac_pe1, cf[S_PE1], g));
-        }
-
-        // ---- backward ----
-        f32x4 g_sc;
+        if (LEVEL <= 2) {
+            // ---- the top layer: g2 from the stored accumulator of g1 ----
+            const f32x4 dsc = io.load_grad(a.dscore, t, f.heads);
+            const f32x4 y_h1 = relu4(pre_of(ac_h1, cf[S_G1], g));
+            const f32x4 ac_sc = mm(wl, 6, lane, y_h1, zero4);
+            const f32x4 pre_sc = pre_of(ac_sc, cf[S_G2], g);
+            f32x4 g_sc;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float sg = 1.f / (1.f + __expf(-pre_sc[r]));
-            g_sc[r] = dsc[r] * sg * (1.f - sg);
-        }
-        if (LEVEL == 1) {
-            s1[0] += g_sc; s2[0] += g_sc * ac_sc;
-        } else {
-            const f32x4 dz_sc = bn_dz(g_sc, ac_sc, cf[S_G2], g);
-            if (LEVEL == 4) {
+            for (int r = 0; r < 4; ++r) {
+                const float sg = 1.f / (1.f + __expf(-pre_sc[r]));
+                g_sc[r] = dsc[r] * sg * (1.f - sg);
+            }
+            if (LEVEL == 1) {
+                s1[0] += g_sc; s2[0] += g_sc * ac_sc;
+            } else {
+                const f32x4 dz_sc = bn_dz(g_sc, ac_sc, cf[S_G2], g);
                 put_tile(tb + 0 * 16 * TT, dz_sc, p, g);
                 put_tile(tb + 1 * 16 * TT, y_h1, p, g);
                 accw[4] = outer(tb + 0 * 16 * TT, tb + 1 * 16 * TT, p, g, accw[4]);
-            }
-            const f32x4 g_h1 = mask_pos(mm(wl, 8, lane, dz_sc, zero4), y_h1);
-            if (LEVEL == 2) {
+                const f32x4 g_h1 = mask_pos(mm(wl, 8, lane, dz_sc, zero4), y_h1);
+                if (g < 2) st4(a.gh1 + (size_t)(t * 16 + p) * CH + 4 * g, make_float4(g_h1[0], g_h1[1], g_h1[2], g_h1[3]));
                 s1[0] += g_h1; s2[0] += g_h1 * ac_h1;
-            } else {
-                f32x4 dq = bn_dz(g_h1, ac_h1, cf[S_G1], g);
-                // z[k] = q[k] - q[key] + b  =>  dq[k] = dz[k] - [k is the key] * (sum over the neighbourhood)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float tot = dq[r];
-                    for (int off = 1; off < f.K; off <<= 1) tot += __shfl_xor(tot, off, WAVE);
-                    if (first) dq[r] -= tot;
-                }
-                if (LEVEL == 4) {
-                    put_tile(tb + 0 * 16 * TT, dq, p, g);
-                    put_tile(tb + 1 * 16 * TT, y_pe0, p, g);
-                    put_tile(tb + 2 * 16 * TT, y_pe1, p, g);
-                    // gradient of the gathered term: consecutive lanes cover the 8 consecutive channels of one row of du
-                    if (g == 0) gi[p] = (int)j_cur;
-                    for (int e = lane; e < 16 * CH; e += WAVE) {
-                        const int r = e / CH, o = e - r * CH;
-                        const int tgt = gi[r];
-                        if (tgt >= 0) atomicAdd(a.du + (size_t)tgt * CH + o, tb[r * TT + o]);
-                    }
-                    accw[2] = outer(tb + 0 * 16 * TT, tb + 1 * 16 * TT, p, g, accw[2]);
-                    accw[3] = outer(tb + 0 * 16 * TT, tb + 2 * 16 * TT, p, g, accw[3]);
-                }
-                const f32x4 g_pe0 = mask_pos(mm(wl, 10, lane, dq, zero4), y_pe0);
-                const f32x4 g_pe1 = mask_pos(mm(wl, 11, lane, dq, zero4), y_pe1);
-                if (LEVEL == 3) {
-                    s1[0] += g_pe0; s2[0] += g_pe0 * ac_pe0;
-                    s1[1] += g_pe1; s2[1] += g_pe1 * ac_pe1;
-                } else {
-                    put_tile(tb + 0 * 16 * TT, bn_dz(g_pe0, ac_pe0, cf[S_PE0], g), p, g);
-                    put_tile(tb + 1 * 16 * TT, bn_dz(g_pe1, ac_pe1, cf[S_PE1], g), p, g);
-                    put_tile(tb + 2 * 16 * TT, x, p, g);
-                    accw[0] = outer(tb + 0 * 16 * TT, tb + 2 * 16 * TT, p, g, accw[0]);
-                    accw[1] = outer(tb + 1 * 16 * TT, tb + 2 * 16 * TT, p, g, accw[1]);
-                }
             }
+            continue;
+        }
+        // ---- passes 3, 4: from the stored g of g1 down through the positional encoding ----
+        const f32x4 g_h1 = io.load_grad(a.gh1, t, CH);
+        const f32x4 x = io.load_x(t);
+        const long long j_cur = LEVEL == 4 ? load_j(t) : -1;
+        const f32x4 ac_pe0 = mm(wl, 0, lane, x, zero4);
+        const f32x4 ac_pe1 = mm(wl, 1, lane, x, zero4);
+        const f32x4 y_pe0 = relu4(pre_of(ac_pe0, cf[S_PE0], g));
+        const f32x4 y_pe1 = relu4(pre_of(ac_pe1, cf[S_PE1], g));
+        f32x4 dq = bn_dz(g_h1, ac_h1, cf[S_G1], g);
+        // z[k] = q[k] - q[key] + b  =>  dq[k] = dz[k] - [k is the key] * (sum over the neighbourhood)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float tot = dq[r];
+            for (int off = 1; off < f.K; off <<= 1) tot += __shfl_xor(tot, off, WAVE);
+            if (first) dq[r] -= tot;
+        }
+        if (LEVEL == 4) {
+            put_tile(tb + 0 * 16 * TT, dq, p, g);
+            put_tile(tb + 1 * 16 * TT, y_pe0, p, g);
+            put_tile(tb + 2 * 16 * TT, y_pe1, p, g);
+            // gradient of the gathered term: consecutive lanes cover the 8 consecutive channels of one row of du
+            if (g == 0) gi[p] = (int)j_cur;
+            for (int e = lane; e < 16 * CH; e += WAVE) {
+                const int r = e / CH, o = e - r * CH;
+                const int tgt = gi[r];
+                if (tgt >= 0) atomicAdd(a.du + (size_t)tgt * CH + o, tb[r * TT + o]);
+            }
+            accw[2] = outer(tb + 0 * 16 * TT, tb + 1 * 16 * TT, p, g, accw[2]);
+            accw[3] = outer(tb + 0 * 16 * TT, tb + 2 * 16 * TT, p, g, accw[3]);
+        }
+        const f32x4 g_pe0 = mask_pos(mm(wl, 10, lane, dq, zero4), y_pe0);
+        const f32x4 g_pe1 = mask_pos(mm(wl, 11, lane, dq, zero4), y_pe1);
+        if (LEVEL == 3) {
+            s1[0] += g_pe0; s2[0] += g_pe0 * ac_pe0;
+            s1[1] += g_pe1; s2[1] += g_pe1 * ac_pe1;
+        } else {
+            put_tile(tb + 0 * 16 * TT, bn_dz(g_pe0, ac_pe0, cf[S_PE0], g), p, g);
+            put_tile(tb + 1 * 16 * TT, bn_dz(g_pe1, ac_pe1, cf[S_PE1], g), p, g);
+            put_tile(tb + 2 * 16 * TT, x, p, g);
+            accw[0] = outer(tb + 0 * 16 * TT, tb + 2 * 16 * TT, p, g, accw[0]);
+            accw[1] = outer(tb + 1 * 16 * TT, tb + 2 * 16 * TT, p, g, accw[1]);
         }
     }
     if (LEVEL == 4) {
-        const int tiles[5] = {0, 1, 3, 4, 6};
+        const int tiles[4] = {0, 1, 3, 4};
         for (int wv = 0; wv < NWAVE; ++wv) {        // wave order: deterministic
             if (wave == wv) {
 #pragma unroll
-                for (int i = 0; i < 5; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) red[tiles[i] * 256 + (4 * g + r) * 16 + p] += accw[i][r];
             }
             __syncthreads();
         }
     } else {
+        if (LEVEL == 2) {                           // dW tile of g2 -> red_top[0]
+            for (int wv = 0; wv < NWAVE; ++wv) {
+                if (wave == wv) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red_top[(4 * g + r) * 16 + p] += accw[4][r];
+                }
+                __syncthreads();
+            }
+        }
         // L1: g2 -> group 0.  L2: g1 -> group 0.  L3: pe lo, pe hi -> groups 0, 1.
         float (*rw)[3][2][16] = reinterpret_cast<float (*)[3][2][16]>(red);
 #pragma unroll
@@ -317,7 +326,7 @@ __device__ __forceinline__ void guidance_branch(const ChainBwdArgs& a, const flo
 //   red (LEVEL < 4): groups {L1: w3 -> 1 | L2: w2 -> 1 | L3: w1 -> 2};   LEVEL 4: dW tiles 2, 5, 7.
 template <int LEVEL>
 __device__ __forceinline__ void weightnet_branch(const ChainBwdArgs& a, const float (*cf)[NCONST][16], const float4* wl,
-                                                 float* red, float* tb, long long t0, long long tstride) {
+                                                 float* red, float* red_top, float* tb, long long t0, long long tstride) {
     const ChainArgs& f = a.f;
     const int lane = lane_id(), wave = wave_id(), p = lane & 15, g = lane >> 4;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -328,59 +337,66 @@ __device__ __forceinline__ void weightnet_branch(const ChainBwdArgs& a, const fl
     for (long long t = t0; t < ntiles; t += tstride) {
         asm volatile("" ::: "memory");
         const f32x4 ac_a2 = io.load_grad(a.a2_acc, t, CH);
-        const f32x4 dwv = io.load_grad(a.dw, t, f.cm);
-        const f32x4 x = LEVEL >= 3 ? io.load_x(t) : zero4;
-        // forward from the stored accumulator of w2; w1 only where its mask / values are needed
-        const f32x4 y_a2 = relu4(pre_of(ac_a2, cf[S_W2], g));
-        const f32x4 ac_w = mm(wl, 7, lane, y_a2, zero4);
-        f32x4 ac_a1 = zero4, y_a1 = zero4;
-        if (LEVEL >= 3) {
-            ac_a1 = mm(wl, 2, lane, x, zero4);
-            y_a1 = relu4(pre_of(ac_a1, cf[S_W1], g));
-        }
-        const f32x4 g_w = mask_pos(dwv, pre_of(ac_w, cf[S_W3], g));
-        if (LEVEL == 1) {
-            s1 += g_w; s2 += g_w * ac_w;
-        } else {
-            const f32x4 dz_w = bn_dz(g_w, ac_w, cf[S_W3], g);
-            if (LEVEL == 4) {
+        if (LEVEL <= 2) {
+            // the top layer: w3 from the stored accumulator of w2
+            const f32x4 dwv = io.load_grad(a.dw, t, f.cm);
+            const f32x4 y_a2 = relu4(pre_of(ac_a2, cf[S_W2], g));
+            const f32x4 ac_w = mm(wl, 7, lane, y_a2, zero4);
+            const f32x4 g_w = mask_pos(dwv, pre_of(ac_w, cf[S_W3], g));
+            if (LEVEL == 1) {
+                s1 += g_w; s2 += g_w * ac_w;
+            } else {
+                const f32x4 dz_w = bn_dz(g_w, ac_w, cf[S_W3], g);
                 put_tile(tb + 0 * 16 * TT, dz_w, p, g);
                 put_tile(tb + 1 * 16 * TT, y_a2, p, g);
                 accw[2] = outer(tb + 0 * 16 * TT, tb + 1 * 16 * TT, p, g, accw[2]);
-            }
-            const f32x4 g_a2 = mask_pos(mm(wl, 9, lane, dz_w, zero4), y_a2);
-            if (LEVEL == 2) {
+                const f32x4 g_a2 = mask_pos(mm(wl, 9, lane, dz_w, zero4), y_a2);
+                if (g < 2) st4(a.ga2 + (size_t)(t * 16 + p) * CH + 4 * g, make_float4(g_a2[0], g_a2[1], g_a2[2], g_a2[3]));
                 s1 += g_a2; s2 += g_a2 * ac_a2;
-            } else {
-                const f32x4 dz_a2 = bn_dz(g_a2, ac_a2, cf[S_W2], g);
-                if (LEVEL == 4) {
-                    put_tile(tb + 0 * 16 * TT, dz_a2, p, g);
-                    put_tile(tb + 1 * 16 * TT, y_a1, p, g);
-                    accw[1] = outer(tb + 0 * 16 * TT, tb + 1 * 16 * TT, p, g, accw[1]);
-                }
-                const f32x4 g_a1 = mask_pos(mm(wl, 12, lane, dz_a2, zero4), y_a1);
-                if (LEVEL == 3) {
-                    s1 += g_a1; s2 += g_a1 * ac_a1;
-                } else {
-                    put_tile(tb + 0 * 16 * TT, bn_dz(g_a1, ac_a1, cf[S_W1], g), p, g);
-                    put_tile(tb + 1 * 16 * TT, x, p, g);
-                    accw[0] = outer(tb + 0 * 16 * TT, tb + 1 * 16 * TT, p, g, accw[0]);
-                }
             }
+            continue;
+        }
+        // passes 3, 4: from the stored g of w2 down through w1
+        const f32x4 g_a2 = io.load_grad(a.ga2, t, CH);
+        const f32x4 x = io.load_x(t);
+        const f32x4 ac_a1 = mm(wl, 2, lane, x, zero4);
+        const f32x4 y_a1 = relu4(pre_of(ac_a1, cf[S_W1], g));
+        const f32x4 dz_a2 = bn_dz(g_a2, ac_a2, cf[S_W2], g);
+        if (LEVEL == 4) {
+            put_tile(tb + 0 * 16 * TT, dz_a2, p, g);
+            put_tile(tb + 1 * 16 * TT, y_a1, p, g);
+            accw[1] = outer(tb + 0 * 16 * TT, tb + 1 * 16 * TT, p, g, accw[1]);
+        }
+        const f32x4 g_a1 = mask_pos(mm(wl, 12, lane, dz_a2, zero4), y_a1);
+        if (LEVEL == 3) {
+            s1 += g_a1; s2 += g_a1 * ac_a1;
+        } else {
+            put_tile(tb + 0 * 16 * TT, bn_dz(g_a1, ac_a1, cf[S_W1], g), p, g);
+            put_tile(tb + 1 * 16 * TT, x, p, g);
+            accw[0] = outer(tb + 0 * 16 * TT, tb + 1 * 16 * TT, p, g, accw[0]);
         }
     }
     if (LEVEL == 4) {
-        const int tiles[3] = {2, 5, 7};
+        const int tiles[2] = {2, 5};
         for (int wv = 0; wv < NWAVE; ++wv) {
             if (wave == wv) {
 #pragma unroll
-                for (int i = 0; i < 3; ++i)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) red[tiles[i] * 256 + (4 * g + r) * 16 + p] += accw[i][r];
             }
             __syncthreads();
         }
     } else {
+        if (LEVEL == 2) {                           // dW tile of w3 -> red_top[1]
+            for (int wv = 0; wv < NWAVE; ++wv) {
+                if (wave == wv) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red_top[256 + (4 * g + r) * 16 + p] += accw[2][r];
+                }
+                __syncthreads();
+            }
+        }
         float (*rw)[3][2][16] = reinterpret_cast<float (*)[3][2][16]>(red);
         const int q = LEVEL == 3 ? 2 : 1;
 #pragma unroll
@@ -411,26 +427,33 @@ __global__ __launch_bounds__(BLOCK) void pcf_chain_bwd_kernel(const ChainBwdArgs
     __shared__ __align__(16) float cf[NSLOT][NCONST][16];
     __shared__ float4 wl[NFRAG * WAVE];
     __shared__ float red[LEVEL == 4 ? NDW * 256 : NWAVE * 96];
-    __shared__ __align__(16) float tbuf[LEVEL == 4 ? NWAVE * 3 * 16 * TT : 4];
+    __shared__ float red_top[LEVEL == 2 ? 2 * 256 : 1];
+    __shared__ __align__(16) float tbuf[LEVEL == 4 ? NWAVE * 3 * 16 * TT : (LEVEL == 2 ? NWAVE * 2 * 16 * TT : 4)];
     __shared__ int gi[NWAVE][16];
     stage_consts(a, cf, LEVEL);
     stage_weights(a, wl);
     for (int t = threadIdx.x; t < (LEVEL == 4 ? NDW * 256 : NWAVE * 96); t += BLOCK) red[t] = 0.f;
+    if (LEVEL == 2)
+        for (int t = threadIdx.x; t < 2 * 256; t += BLOCK) red_top[t] = 0.f;
     __syncthreads();
     const int wave = wave_id();
-    float* tb = LEVEL == 4 ? tbuf + wave * 3 * 16 * TT : tbuf;
+    float* tb = LEVEL == 4 ? tbuf + wave * 3 * 16 * TT : (LEVEL == 2 ? tbuf + wave * 2 * 16 * TT : tbuf);
     constexpr int NG = SplitOf<LEVEL>::NG;
     const int rank = branch_rank<NG>(blockIdx.x);
     if (is_guidance_block<NG>(blockIdx.x))
-        guidance_branch<LEVEL>(a, cf, wl, red, tb, gi[wave], (long long)rank * NWAVE + wave, (long long)grid8 * NG * NWAVE);
+        guidance_branch<LEVEL>(a, cf, wl, red, red_top, tb, gi[wave], (long long)rank * NWAVE + wave, (long long)grid8 * NG * NWAVE);
     else
-        weightnet_branch<LEVEL>(a, cf, wl, red, tb, (long long)rank * NWAVE + wave, (long long)grid8 * (8 - NG) * NWAVE);
+        weightnet_branch<LEVEL>(a, cf, wl, red, red_top, tb, (long long)rank * NWAVE + wave, (long long)grid8 * (8 - NG) * NWAVE);
     if (LEVEL == 4) {
         float* outp = a.part + (size_t)blockIdx.x * (NDW * 256);
         for (int u = threadIdx.x; u < NDW * 256; u += BLOCK) outp[u] = red[u];
         return;
     }
     __syncthreads();
+    if (LEVEL == 2) {
+        float* outp = a.part_top + (size_t)blockIdx.x * 512;
+        for (int u = threadIdx.x; u < 512; u += BLOCK) outp[u] = red_top[u];
+    }
     if (threadIdx.x < 96) {
         const float (*rw)[3][2][16] = reinterpret_cast<const float (*)[3][2][16]>(red);
         const int q = threadIdx.x / 32, which = (threadIdx.x >> 4) & 1, c = threadIdx.x & 15;
@@ -484,7 +507,7 @@ __global__ __launch_bounds__(1024) void chain_bwd_finalize_kernel(const BwdFinAr
 // dW of the six layers from the per-workgroup 16x16 tiles of pass 4; one workgroup per 64 tile elements,
 // 16 slices of the partial list each (fixed order).
 struct BwdParamArgs {
-    const float* part; int nblocks;
+    const float* part; const float* part_top; int nblocks;
     float* dW[6];
     float* db[6];               // written as zeros (bias in front of a training-mode BatchNorm)
     int cv, g, heads, cm;
@@ -494,15 +517,19 @@ __global__ __launch_bounds__(1024) void chain_bwd_params_kernel(const BwdParamAr
     __shared__ float sh[16][64];
     const int e = blockIdx.x * 64 + (threadIdx.x & 63);        // element of the [NDW][16][16] tile set
     const int slice = threadIdx.x >> 6;
+    // tiles 6, 7 (g2, w3) were accumulated by pass 2 (part_top, 2 tiles per workgroup), the rest by pass 4
+    const bool top = (e >> 8) >= 6;
+    const float* src = top ? f.part_top + (e - 6 * 256) : f.part + e;
+    const size_t stride = top ? 512 : NDW * 256;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     int p = slice;
     for (; p + 48 < f.nblocks; p += 64) {
-        a0 += f.part[(size_t)p * (NDW * 256) + e];
-        a1 += f.part[(size_t)(p + 16) * (NDW * 256) + e];
-        a2 += f.part[(size_t)(p + 32) * (NDW * 256) + e];
-        a3 += f.part[(size_t)(p + 48) * (NDW * 256) + e];
+        a0 += src[(size_t)p * stride];
+        a1 += src[(size_t)(p + 16) * stride];
+        a2 += src[(size_t)(p + 32) * stride];
+        a3 += src[(size_t)(p + 48) * stride];
     }
-    for (; p < f.nblocks; p += 16) a0 += f.part[(size_t)p * (NDW * 256) + e];
+    for (; p < f.nblocks; p += 16) a0 += src[(size_t)p * stride];
     sh[slice][threadIdx.x & 63] = (a0 + a1) + (a2 + a3);
     __syncthreads();
     if (blockIdx.x == 0 && threadIdx.x >= 64 && threadIdx.x < 64 + 6 * 32) {
@@ -531,8 +558,10 @@ __global__ __launch_bounds__(1024) void chain_bwd_params_kernel(const BwdParamAr
 
 extern "C" {
 
-size_t pcf_hip_pcf_chain_backward_workspace_bytes(void) {
-    return ((size_t)1024 * pcf::NDW * 256 + 12 * 64) * 4 + 1024;
+size_t pcf_hip_pcf_chain_backward_workspace_bytes(long long E) {
+    // per-workgroup partials of passes 1-4, the 12 x 64 per-channel means, and the two [E, 8] gradients pass 2 hands
+    // to passes 3-4
+    return ((size_t)1024 * pcf::NDW * 256 + (size_t)1024 * 512 + 12 * 64) * 4 + (size_t)(E > 0 ? E : 0) * 2 * pcf::CH * 4 + 1024;
 }
 
 int pcf_hip_pcf_chain_backward(const float* vi, const int64_t* idx, const float* h1_acc, const float* a2_acc,
@@ -568,7 +597,7 @@ int pcf_hip_pcf_chain_backward(const float* vi, const int64_t* idx, const float*
     PCF_REQUIRE(vi && idx && h1_acc && a2_acc && dscore && dw, "pcf_chain_backward: null pointer");
     PCF_REQUIRE(aligned16(h1_acc) && aligned16(a2_acc) && aligned16(dscore) && aligned16(dw) && aligned16(du),
                 "pcf_chain_backward: buffers must be 16-byte aligned");
-    PCF_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= pcf_hip_pcf_chain_backward_workspace_bytes(),
+    PCF_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= pcf_hip_pcf_chain_backward_workspace_bytes(E),
                 "pcf_chain_backward: workspace too small or misaligned");
     PCF_REQUIRE(batches * N < (1ll << 31), "pcf_chain_backward: too many points");
     ChainBwdArgs a{};
@@ -577,6 +606,9 @@ int pcf_hip_pcf_chain_backward(const float* vi, const int64_t* idx, const float*
     a.f.vec_vi = (cv % 4 == 0) && aligned16(vi);
     float* means = static_cast<float*>(workspace);           // [12][64]: mean g, then mean g*xhat, per layer
     a.part = means + 12 * 64;
+    a.part_top = a.part + (size_t)1024 * NDW * 256;
+    a.gh1 = a.part_top + (size_t)1024 * 512;           // 16-byte aligned: every region is a multiple of 64 floats
+    a.ga2 = a.gh1 + (size_t)E * CH;
     for (int l = 0; l < 6; ++l) {
         a.f.W[l] = W[l]; a.f.b[l] = b[l]; a.f.gamma[l] = gamma[l]; a.f.beta[l] = beta[l];
         a.f.mean[l] = stats + l * 64; a.f.rstd[l] = stats + (6 + l) * 64;
@@ -608,7 +640,7 @@ int pcf_hip_pcf_chain_backward(const float* vi, const int64_t* idx, const float*
     hipLaunchKernelGGL(pcf_chain_bwd_kernel<4>, dim3(grid), dim3(BLOCK), 0, s, a, grid / 8);
     if (int e = check_launch("pcf_chain_backward final pass")) return e;
     BwdParamArgs pa{};
-    pa.part = a.part; pa.nblocks = grid; pa.cv = cv; pa.g = g; pa.heads = heads; pa.cm = cm;
+    pa.part = a.part; pa.part_top = a.part_top; pa.nblocks = grid; pa.cv = cv; pa.g = g; pa.heads = heads; pa.cm = cm;
     for (int l = 0; l < 6; ++l) { pa.dW[l] = dW[l]; pa.db[l] = db[l]; }
     hipLaunchKernelGGL(chain_bwd_params_kernel, dim3(NDW * 256 / 64), dim3(1024), 0, s, pa);
     return check_launch("pcf_chain_backward parameter reduction");

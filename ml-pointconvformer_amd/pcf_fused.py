@@ -404,7 +404,7 @@ _chain_fwd = _sig('pcf_hip_pcf_chain_forward',
 
 
 _chain_bwd_ws = getattr(_lib, 'pcf_hip_pcf_chain_backward_workspace_bytes')
-_chain_bwd_ws.argtypes = []
+_chain_bwd_ws.argtypes = [_LL]
 _chain_bwd_ws.restype = _Z
 _chain_bwd = _sig('pcf_hip_pcf_chain_backward',
                   [_P, _P, _P, _P, _P, _P, _LL, _LL, _I, _I, _I, _I, _I, _I, _PP, _PP, _PP, _PP, _P, _P, _PP, _PP, _PP, _PP,
@@ -505,7 +505,7 @@ class _PCFChain(torch.autograd.Function):
                 dfx, dscore, dw = pcf_cuda.pcf_backward(dagg.contiguous(), fx, idx, score, w)
                 du = torch.empty_like(u)
                 grads = [torch.empty_like(t) for t in keep]
-                nbytes = _chain_bwd_ws()
+                nbytes = _chain_bwd_ws(B * M * K)
                 ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
                 _call(_chain_bwd, _ptr(vi), _ptr(idx), _ptr(h1_acc), _ptr(a2_acc), _ptr(dscore), _ptr(dw), B * M * K, M * K,
                       u.shape[1], K, cv,
