@@ -418,9 +418,10 @@ template <int NG> __device__ __host__ inline int branch_rank(int b) {
 template <int NG> __host__ inline int branch_blocks(int grid, bool guidance) {       // grid is a multiple of 8
     return guidance ? (grid >> 3) * NG : (grid >> 3) * (8 - NG);
 }
-// matrix instructions per tile, guidance : WeightNet = 4 : 4 (pass 1), 8 : 8 (pass 2), 24 : 16 (pass 3), 44 : 28 (pass 4);
-// measured: 5 of 8 is best for passes 3-4 (6: +15 %) and within noise of 4 of 8 for the memory-bound passes 1-2
-template <int LEVEL> struct SplitOf { static constexpr int NG = 5; };
+// matrix instructions per tile, guidance : WeightNet = 4 : 4 (pass 1), 12 : 12 (pass 2), 16 : 8 (pass 3), 32 : 16 (pass 4).
+// Measured: passes 1-3 do not care between 4 and 6 of 8 (they are closer to the memory side); pass 4 is 8 % faster
+// with 6 of 8 than with 5.
+template <int LEVEL> struct SplitOf { static constexpr int NG = LEVEL == 4 ? 6 : 5; };
 
 template <int LEVEL>
 __global__ __launch_bounds__(BLOCK) void pcf_chain_bwd_kernel(const ChainBwdArgs a, int grid8) {
