@@ -8,18 +8,18 @@
 // (layers.py:361-384 with MultiHeadGuidance :47-68 and WeightNet :163-171; u = Wa.guidance_x is the
 // per-point half of the first guidance layer, see pcf_hip_rowlin_*_ex.)  In training every BatchNorm
 // needs the statistics of its pre-activation over ALL edges before the next layer can run, which is
-// three dependent global reductions.  Layer-at-a-time execution (edge_mlp.hip) costs 12 kernels that
-// stream [E, 8..32] activations back and forth; here the chain is RECOMPUTED from the 48-byte VI row in
-// each of four passes, a pass ending at the first layer whose statistics are still unknown:
-//     pass 1: statistics of mlp_conv and w1                      (reads VI)
-//     pass 2: writes pe, a1;  statistics of g1 and w2            (reads VI, idx, u)
-//     pass 3: writes h1, a2;  statistics of g2 and w3
-//     pass 4: writes score, w                                    (the aggregate kernel consumes them)
-// The activations are written once because the backward kernels need them; in inference (running
-// statistics) only pass 4 runs and nothing but score and w is written.  One lane owns one edge; all six
-// weight matrices sit in LDS (5 KB) and are read as wave-wide broadcasts; per-channel sums go through
-// the same 64x16 LDS transposition as edge_mlp.hip.  HBM-bound: 4 x 48 B + 3 x 40 B read, 392 B written
-// per edge at the BASELINE shape against ~2 kB for the layer-at-a-time path.
+// three dependent global reductions.  Layer-at-a-time execution (edge_mlp_mfma.hip) costs 12 kernels that
+// stream [E, 8..32] activations back and forth (~2 kB per edge); here:
+//     pass 1: statistics of mlp_conv and w1                      (reads the 48-byte VI row)
+//     pass 2: recomputes them, runs g1 and w2, takes their statistics and stores their raw 8-channel
+//             accumulators (2 x 32 B per edge)                   (reads VI, idx, u)
+//     pass 3: statistics of g2 and w3 from the stored accumulators      (pcf_chain_tail_kernel<true>)
+//     pass 4: score and w from the stored accumulators                  (pcf_chain_tail_kernel<false>)
+// The two stored accumulators are also where the fused backward (edge_chain_bwd.hip) restarts.  Callers that
+// want the layer-at-a-time backward instead get pe / a1 / h1 / a2 written by the full-recompute passes
+// (pcf_chain_kernel<3>, <4>); in inference (running statistics) only pcf_chain_kernel<4> runs and nothing but
+// score and w is written.  The chain kernels are fp32-ALU-bound (the fp32 MFMA shares the VALU's lanes), the
+// tail kernels HBM-bound.
 #include <algorithm>
 
 #include "edge_chain.h"
