@@ -23,8 +23,13 @@ def setup(backend=None):
     """Join the process group described by RANK / WORLD_SIZE / MASTER_* (no-op for one process).
     Returns (rank, world_size, local_rank, device)."""
     rank, world, local_rank = env_rank()
-    use_gpu = torch.cuda.is_available() and backend != 'gloo'
-    dev = torch.device('cuda', local_rank) if use_gpu else torch.device('cpu')
+    # Rehearsal on a one-GPU box: PCF_DIST_REHEARSE=1 puts every rank on cuda:0 and uses gloo for the collectives
+    # (RCCL refuses two ranks on one device).  Never set by bench.py or the tests' normal paths.
+    rehearse = os.environ.get('PCF_DIST_REHEARSE') == '1'
+    if rehearse:
+        backend = 'gloo'
+    use_gpu = torch.cuda.is_available() and (backend != 'gloo' or rehearse)
+    dev = torch.device('cuda', 0 if rehearse else local_rank) if use_gpu else torch.device('cpu')
     if use_gpu:
         torch.cuda.set_device(dev)
     if world > 1 and not dist.is_initialized():
