@@ -156,11 +156,18 @@ __global__ __launch_bounds__(BLOCK) void rowlin_mfma_stats_kernel(const RowLin a
 #pragma unroll
     for (int to = 0; to < TO; ++to) { s1[to] = f32x4{0.f, 0.f, 0.f, 0.f}; s2[to] = s1[to]; }
     const long long ntiles = (a.R + 15) / 16;
-    for (long long t = (long long)blockIdx.x * NWAVE + wave; t < ntiles; t += (long long)gridDim.x * NWAVE) {
+    // the rows of the next tile are requested before this one is processed (short inputs are latency-bound)
+    const long long tstep = (long long)gridDim.x * NWAVE;
+    long long t = (long long)blockIdx.x * NWAVE + wave;
+    f32x4 xn[TI];
+    load_rows<TI>(a, t * 16 + p, t * 16 + p < a.R, g, xn);
+    for (; t < ntiles; t += tstep) {
         const long long row = t * 16 + p;
         const bool valid = row < a.R;
         f32x4 x[TI], z[TO];
-        load_rows<TI>(a, row, valid, g, x);
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti) x[ti] = xn[ti];
+        if (t + tstep < ntiles) load_rows<TI>(a, (t + tstep) * 16 + p, (t + tstep) * 16 + p < a.R, g, xn);
         long long grow;
         pre_activation<TI, TO>(a, w, x, row, valid, lane, p, g, sv, grow, z);
         const float m = valid ? 1.f : 0.f;
@@ -186,11 +193,18 @@ __global__ __launch_bounds__(BLOCK) void rowlin_mfma_fwd_kernel(const RowLin a) 
     load_weights<TI, TO>(a, p, g, w);
     const bool bn = a.mean != nullptr;
     const long long ntiles = (a.R + 15) / 16;
-    for (long long t = (long long)blockIdx.x * NWAVE + wave; t < ntiles; t += (long long)gridDim.x * NWAVE) {
+    // the rows of the next tile are requested before this one is processed (short inputs are latency-bound)
+    const long long tstep = (long long)gridDim.x * NWAVE;
+    long long t = (long long)blockIdx.x * NWAVE + wave;
+    f32x4 xn[TI];
+    load_rows<TI>(a, t * 16 + p, t * 16 + p < a.R, g, xn);
+    for (; t < ntiles; t += tstep) {
         const long long row = t * 16 + p;
         const bool valid = row < a.R;
         f32x4 x[TI], z[TO];
-        load_rows<TI>(a, row, valid, g, x);
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti) x[ti] = xn[ti];
+        if (t + tstep < ntiles) load_rows<TI>(a, (t + tstep) * 16 + p, (t + tstep) * 16 + p < a.R, g, xn);
         long long grow;
         pre_activation<TI, TO>(a, w, x, row, valid, lane, p, g, sv, grow, z);
         if (!valid) continue;
@@ -215,23 +229,34 @@ __global__ __launch_bounds__(BLOCK) void rowlin_mfma_fwd_kernel(const RowLin a) 
     }
 }
 
+// upstream gradient of the four channels of every output tile held by this lane (zeros outside the matrix)
+template <int TO>
+__device__ __forceinline__ void load_dy(const RowLin& a, long long row, bool valid, int g, f32x4 (&dv)[TO]) {
+#pragma unroll
+    for (int to = 0; to < TO; ++to) {
+        const int c0 = 16 * to + 4 * g;
+        dv[to] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!valid || c0 >= a.Cout) continue;
+        const float* q = a.dy + (size_t)row * a.Cout + c0;
+        if (a.vec_y) { const float4 v = ld4(q); dv[to][0] = v.x; dv[to][1] = v.y; dv[to][2] = v.z; dv[to][3] = v.w; }
+        else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dv[to][r] = (c0 + r < a.Cout) ? q[r] : 0.f;
+        }
+    }
+}
+
 // g = dy * act'(u) and xhat for the four channels of tile `to` held by this lane
 template <int TO>
-__device__ __forceinline__ void grad_terms(const RowLin& a, const f32x4 (&z)[TO], long long row, bool valid, int g, bool bn,
-                                           const float (*sv)[64], f32x4 (&gr)[TO], f32x4 (&xh)[TO]) {
+__device__ __forceinline__ void grad_terms(const RowLin& a, const f32x4 (&z)[TO], const f32x4 (&dv)[TO], bool valid, int g,
+                                           bool bn, const float (*sv)[64], f32x4 (&gr)[TO], f32x4 (&xh)[TO]) {
 #pragma unroll
     for (int to = 0; to < TO; ++to) {
         const int c0 = 16 * to + 4 * g;
         gr[to] = f32x4{0.f, 0.f, 0.f, 0.f};
         xh[to] = gr[to];
         if (!valid || c0 >= a.Cout) continue;
-        const float* q = a.dy + (size_t)row * a.Cout + c0;
-        float d[4];
-        if (a.vec_y) { const float4 v = ld4(q); d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; }
-        else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) d[r] = (c0 + r < a.Cout) ? q[r] : 0.f;
-        }
+        const f32x4 d = dv[to];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             if (c0 + r >= a.Cout) continue;
@@ -259,14 +284,26 @@ __global__ __launch_bounds__(BLOCK) void rowlin_mfma_bwd_reduce_kernel(const Row
 #pragma unroll
     for (int to = 0; to < TO; ++to) { s1[to] = f32x4{0.f, 0.f, 0.f, 0.f}; s2[to] = s1[to]; }
     const long long ntiles = (a.R + 15) / 16;
-    for (long long t = (long long)blockIdx.x * NWAVE + wave; t < ntiles; t += (long long)gridDim.x * NWAVE) {
+    const long long tstep = (long long)gridDim.x * NWAVE;
+    long long t = (long long)blockIdx.x * NWAVE + wave;
+    f32x4 xn[TI], dn[TO];
+    load_rows<TI>(a, t * 16 + p, t * 16 + p < a.R, g, xn);
+    load_dy<TO>(a, t * 16 + p, t * 16 + p < a.R, g, dn);
+    for (; t < ntiles; t += tstep) {
         const long long row = t * 16 + p;
         const bool valid = row < a.R;
-        f32x4 x[TI], z[TO], gr[TO], xh[TO];
-        load_rows<TI>(a, row, valid, g, x);
+        f32x4 x[TI], dv[TO], z[TO], gr[TO], xh[TO];
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti) x[ti] = xn[ti];
+#pragma unroll
+        for (int to = 0; to < TO; ++to) dv[to] = dn[to];
+        if (t + tstep < ntiles) {
+            load_rows<TI>(a, (t + tstep) * 16 + p, (t + tstep) * 16 + p < a.R, g, xn);
+            load_dy<TO>(a, (t + tstep) * 16 + p, (t + tstep) * 16 + p < a.R, g, dn);
+        }
         long long grow;
         pre_activation<TI, TO>(a, w, x, row, valid, lane, p, g, sv, grow, z);
-        grad_terms<TO>(a, z, row, valid, g, true, sv, gr, xh);
+        grad_terms<TO>(a, z, dv, valid, g, true, sv, gr, xh);
 #pragma unroll
         for (int to = 0; to < TO; ++to)
 #pragma unroll
@@ -311,14 +348,26 @@ __global__ __launch_bounds__(BLOCK) void rowlin_mfma_bwd_apply_kernel(const RowL
         for (int ti = 0; ti < TI; ++ti) accw[to][ti] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const long long ntiles = (a.R + 15) / 16;
-    for (long long t = (long long)blockIdx.x * NWAVE + wave; t < ntiles; t += (long long)gridDim.x * NWAVE) {
+    const long long tstep = (long long)gridDim.x * NWAVE;
+    long long t = (long long)blockIdx.x * NWAVE + wave;
+    f32x4 xn[TI], dn[TO];
+    load_rows<TI>(a, t * 16 + p, t * 16 + p < a.R, g, xn);
+    load_dy<TO>(a, t * 16 + p, t * 16 + p < a.R, g, dn);
+    for (; t < ntiles; t += tstep) {
         const long long row = t * 16 + p;
         const bool valid = row < a.R;
-        f32x4 x[TI], z[TO], dz[TO], xh[TO];
-        load_rows<TI>(a, row, valid, g, x);
+        f32x4 x[TI], dv[TO], z[TO], dz[TO], xh[TO];
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti) x[ti] = xn[ti];
+#pragma unroll
+        for (int to = 0; to < TO; ++to) dv[to] = dn[to];
+        if (t + tstep < ntiles) {
+            load_rows<TI>(a, (t + tstep) * 16 + p, (t + tstep) * 16 + p < a.R, g, xn);
+            load_dy<TO>(a, (t + tstep) * 16 + p, (t + tstep) * 16 + p < a.R, g, dn);
+        }
         long long grow;
         pre_activation<TI, TO>(a, w, x, row, valid, lane, p, g, sv, grow, z);
-        grad_terms<TO>(a, z, row, valid, g, bn, sv, dz, xh);
+        grad_terms<TO>(a, z, dv, valid, g, bn, sv, dz, xh);
 #pragma unroll
         for (int to = 0; to < TO; ++to)
 #pragma unroll
