@@ -422,7 +422,7 @@ static int make_plan(Plan& pl, bool backward, bool guided, int total, int K, int
     // exposed in each, so it wants resident workgroups more than amortisation: 4 points (one per wave, ~22 KB of
     // LDS, 7 workgroups per CU) measured 122 us against 154 us with 8 points at N = 80k; the forward (one staging
     // phase) is fastest with 8.
-    const int pmax = backward ? NWAVE : 8;
+    const int pmax = (backward && guided) ? NWAVE : 8;       // the unguided (PConv, C_mid = 1) backward measured faster with 8
     int P = (int)((LDS_BUDGET / 4 - slack) / per_pt);
     if (P < 1) P = 1;
     if (P > pmax) P = pmax;

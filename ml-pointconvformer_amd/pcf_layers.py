@@ -56,7 +56,7 @@ class PCFFunction(torch.autograd.Function):
         return gi, None, gg, gw, None, None, None
 
 
-class PCF(nn.Module):
+class PCF(pcf_fused.CounterScope):
     """(layer_utils.py:109-124)"""
 
     @staticmethod
@@ -85,7 +85,7 @@ def _empty_additional(input_features, neighbor_inds):
     return input_features.new_zeros(B, Nout, K, 0)
 
 
-class PConv(nn.Module):
+class PConv(pcf_fused.CounterScope):
     """(layer_utils.py:156-173)"""
 
     @staticmethod
@@ -117,7 +117,7 @@ class PConvLinearOptFunction(torch.autograd.Function):
         return g[0], None, None, None, None, g[1], g[2], g[3], g[4]
 
 
-class PConvLinearOpt(nn.Module):
+class PConvLinearOpt(pcf_fused.CounterScope):
     """(layer_utils.py:73-86)"""
 
     def __init__(self, in_features, out_features):
@@ -151,7 +151,7 @@ def VI_coordinate_transform(localized_xyz, gathered_norm, sparse_xyz_norm, K=Non
 # --------------------------------------------------------------------------------------------------
 # Linear_BN / UnaryBlock (layer_utils.py:241-319)
 # --------------------------------------------------------------------------------------------------
-class Linear_BN(nn.Module):
+class Linear_BN(pcf_fused.CounterScope):
     """Linear followed by BatchNorm over every axis but the last.  ``bn_ver`` is accepted for
     signature compatibility; both versions normalise the channel (last) axis."""
 
@@ -204,7 +204,7 @@ def _linear_act(layer, x, act):
     return pcf_fused.wide_linear_bn_act(x, layer.weight, layer.bias, None, act, layer.training)
 
 
-class UnaryBlock(nn.Module):
+class UnaryBlock(pcf_fused.CounterScope):
     def __init__(self, in_dim, out_dim, use_bn, bn_momentum, no_relu=False):
         super().__init__()
         self.in_dim, self.out_dim, self.use_bn, self.no_relu = in_dim, out_dim, use_bn, no_relu
@@ -224,7 +224,7 @@ class UnaryBlock(nn.Module):
 # --------------------------------------------------------------------------------------------------
 # per-edge MLPs (layers.py:23-68, 127-191)
 # --------------------------------------------------------------------------------------------------
-class MultiHeadGuidance(nn.Module):
+class MultiHeadGuidance(pcf_fused.CounterScope):
     """sigmoid(MLP_{C -> 8 -> heads}(query - key)), ReLU between the two layers."""
 
     def __init__(self, cfg, num_heads: int, num_hiddens: int):
@@ -267,7 +267,7 @@ class MultiHeadGuidance(nn.Module):
         return s
 
 
-class WeightNet(nn.Module):
+class WeightNet(pcf_fused.CounterScope):
     """Linear_BN + ReLU after every layer, the last one included."""
 
     def __init__(self, in_channel, out_channel, hidden_unit=(8, 8), efficient=False):
@@ -303,7 +303,7 @@ def _drop_path(cfg):
     return nn.Identity()
 
 
-class PCFLayer(nn.Module):
+class PCFLayer(pcf_fused.CounterScope):
     """PointConvFormer layer.  (layers.py:194-416)"""
 
     def __init__(self, in_channel, out_channel, cfg, weightnet=[9, 16], num_heads=4, guidance_feat_len=32):
@@ -389,7 +389,7 @@ class PCFLayer(nn.Module):
         return new_feat, wn_in
 
 
-class _ConvTail(nn.Module):
+class _ConvTail(pcf_fused.CounterScope):
     """Shared tail of the PointConv family: aggregate + linear, chosen by PCONV_OPT / USE_CUDA_KERNEL."""
 
     def _build_linear(self, cfg, in_features, out_features):

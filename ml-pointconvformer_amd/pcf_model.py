@@ -65,7 +65,7 @@ def _inv(triple, i):
     return dict(inv_neighbors=triple[0][i], inv_k=triple[1][i], inv_idx=triple[2][i])
 
 
-class PCF_Backbone(nn.Module):
+class PCF_Backbone(pcf_fused.CounterScope):
     def __init__(self, cfg, input_feat_dim=3):
         super().__init__()
         if cfg.transformer_type != 'PCF':
@@ -121,7 +121,7 @@ class PCF_Backbone(nn.Module):
         return feats
 
 
-class PointConvFormer_Segmentation(nn.Module):
+class PointConvFormer_Segmentation(pcf_fused.CounterScope):
     def __init__(self, cfg):
         super().__init__()
         self.cfg = cfg
