@@ -24,6 +24,10 @@
 
 #include "edge_chain.h"
 
+// fused multiply-adds in the per-element BatchNorm algebra, as in edge_chain_bwd.hip (the library default is
+// contraction off): the backward recomputes the first layers with the same rounding
+#pragma clang fp contract(fast)
+
 namespace pcf {
 
 // BatchNorm constants of output-tile slot `f` (0 pe lo, 1 pe hi, 2 w1, 3 g1, 4 w2, 5 g2, 6 w3), channel c of the
