@@ -466,6 +466,68 @@ def test_wide_linear_bn_act_against_torch(device, rows, cin, cout, act, bn, trai
         torch.testing.assert_close(bn_d.running_var.cpu(), ref_bn.running_var.float(), rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize('rows,cin,cout,act,bn,training', [(5000, 32, 64, 2, True, True), (999, 128, 256, 2, True, True),
+                                                          (640, 96, 70, 1, False, True), (300, 160, 64, 2, True, False)])
+def test_wide_linear_bn_act_with_residual(device, rows, cin, cout, act, bn, training):
+    """y = act(BN(x W^T + b) + residual) in the column-BN kernels (the tail of every residual block) vs torch fp64:
+    output and the gradients of x, the residual and all parameters."""
+    import copy
+    import pcf_fused
+    g = torch.Generator().manual_seed(rows + cout)
+    x = torch.randn(1, rows, cin, generator=g) + 0.2
+    res = torch.randn(1, rows, cout, generator=g)
+    lin = torch.nn.Linear(cin, cout)
+    bnm = torch.nn.BatchNorm1d(cout) if bn else None
+    if bn:
+        with torch.no_grad():
+            bnm.weight.copy_(torch.rand(cout, generator=g) + 0.5)
+            bnm.bias.copy_(torch.randn(cout, generator=g) * 0.2)
+            bnm.running_var.copy_(torch.rand(cout, generator=g) + 0.5)
+    lin_d, bn_d = copy.deepcopy(lin).to(device), (copy.deepcopy(bnm).to(device).train(training) if bn else None)
+    ref_lin, ref_bn = copy.deepcopy(lin).double(), (copy.deepcopy(bnm).double().train(training) if bn else None)
+    actf = {1: torch.relu, 2: lambda t: torch.nn.functional.leaky_relu(t, 0.1)}[act]
+    xr, rr = x.double().requires_grad_(True), res.double().requires_grad_(True)
+    zz = ref_lin(xr)
+    if bn:
+        zz = ref_bn(zz.reshape(-1, cout)).view(zz.shape)
+    want = actf(zz + rr)
+    up = torch.randn(want.shape, generator=g)
+    want.backward(up.double())
+    xd, rd = x.to(device).requires_grad_(True), res.to(device).requires_grad_(True)
+    got = pcf_fused.wide_linear_bn_act(xd, lin_d.weight, lin_d.bias, bn_d, act, training, residual=rd)
+    got.backward(up.to(device))
+    tol = dict(rtol=3e-4, atol=3e-4)
+    torch.testing.assert_close(got.cpu(), want.float(), **tol)
+    torch.testing.assert_close(xd.grad.cpu(), xr.grad.float(), **tol)
+    torch.testing.assert_close(rd.grad.cpu(), rr.grad.float(), **tol)
+    sc = max(1.0, float(ref_lin.weight.grad.abs().max()))
+    torch.testing.assert_close(lin_d.weight.grad.cpu(), ref_lin.weight.grad.float(), rtol=3e-4, atol=3e-4 * sc)
+    if bn:
+        torch.testing.assert_close(bn_d.weight.grad.cpu(), ref_bn.weight.grad.float(), rtol=3e-4, atol=3e-4 * sc)
+        torch.testing.assert_close(bn_d.bias.grad.cpu(), ref_bn.bias.grad.float(), rtol=3e-4, atol=3e-4 * sc)
+
+
+@pytest.mark.parametrize('B,M,K', [(1, 1000, 16), (2, 37, 5), (1, 4, 16), (3, 211, 16)])
+def test_edge_geometry_store_paths(device, B, M, K):
+    """The VI rows leave the kernel as contiguous KiB per full wave and row by row in the ragged last wave: both paths,
+    edge counts that are and are not multiples of 64, against the oracle."""
+    import pcf_fused
+    from oracle import pcf_oracle as O
+    g = torch.Generator().manual_seed(B * 1000 + M)
+    N = max(M, K) + 5
+    xyz, nrm = torch.rand(B, N, 3, generator=g), torch.nn.functional.normalize(torch.randn(B, N, 3, generator=g), dim=-1)
+    cxyz, cnrm = torch.rand(B, M, 3, generator=g), torch.nn.functional.normalize(torch.randn(B, M, 3, generator=g), dim=-1)
+    idx = torch.randint(0, N, (B, M, K), generator=g)
+    d = lambda t: t.to(device)
+    for want_rel in (True, False):
+        rel, vi = pcf_fused.edge_geometry(d(xyz), d(nrm), d(idx), d(cxyz), d(cnrm), want_rel=want_rel)
+        wrel = O.gather_rows(xyz, idx) - cxyz.unsqueeze(2)
+        assert (rel is None) == (not want_rel)
+        if want_rel:
+            torch.testing.assert_close(rel.cpu(), wrel, rtol=0, atol=0)
+        torch.testing.assert_close(vi.cpu(), O.vi_features(wrel, O.gather_rows(nrm, idx), cnrm), rtol=1e-4, atol=1e-5)
+
+
 def test_fused_edge_chain_inference(device):
     """eval(): the chain runs its single inference pass on the running statistics.  Against the layer-at-a-time
     kernels, after one training step so the running statistics moved (they are compared too).  (PCFLayer needs the
