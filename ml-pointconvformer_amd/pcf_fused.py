@@ -399,10 +399,14 @@ class _WideLinearBNAct(torch.autograd.Function):
                 dres = dy if residual is not None else None
             dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
             dW = torch.empty_like(W)
-            db = torch.empty(Cout, dtype=torch.float32, device=dev)
+            # a bias in front of a batch-statistics BatchNorm has an identically zero gradient (the mean subtraction
+            # cancels it): no column sums of dz, exact zeros instead of their rounding noise
+            zero_db = bn and training
+            db = torch.zeros(Cout, dtype=torch.float32, device=dev) if zero_db else torch.empty(Cout, dtype=torch.float32, device=dev)
             nbytes = _linbwd_ws(R, Cin, Cout)
             ws2 = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            _call(_linbwd, _ptr(dz), _ptr(x), _ptr(W), R, Cin, Cout, _ptr(dx), _ptr(dW), _ptr(db), ws2.data_ptr(), nbytes, stream)
+            _call(_linbwd, _ptr(dz), _ptr(x), _ptr(W), R, Cin, Cout, _ptr(dx), _ptr(dW), None if zero_db else _ptr(db),
+                  ws2.data_ptr(), nbytes, stream)
         return dx, dW, db, dgamma, dbeta, None, None, None, None, None, None, dres
 
 
