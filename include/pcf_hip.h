@@ -231,13 +231,14 @@ int pcf_hip_bnact_backward(const float* z, const float* dy, long long R, int C, 
                            const float* gamma, const float* beta, int batch_stats, int act, float* dz,
                            float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
 /* The same with a residual branch (leaky_relu(unary2(.) + shortcut), layers.py:408-416 / :737-741): y = act(BN(z) +
- * residual); backward also returns dresidual = dy * act'(.) (nullable). */
+ * residual); backward also returns dresidual = dy * act'(.) (nullable) and, with batch statistics, writes C zeros
+ * to dbias_zero (nullable): the gradient of the Linear bias that feeds this BatchNorm. */
 int pcf_hip_bnact_forward_res(const float* z, const float* residual, long long R, int C, const float* mean,
                               const float* rstd, const float* gamma, const float* beta, int act, float* y, void* stream);
 int pcf_hip_bnact_backward_res(const float* z, const float* residual, const float* dy, long long R, int C, const float* mean,
                                const float* rstd, const float* gamma, const float* beta, int batch_stats, int act,
-                               float* dz, float* dresidual, float* dgamma, float* dbeta, void* workspace,
-                               size_t workspace_bytes, void* stream);
+                               float* dz, float* dresidual, float* dgamma, float* dbeta, float* dbias_zero,
+                               void* workspace, size_t workspace_bytes, void* stream);
 size_t pcf_hip_linear_backward_workspace_bytes(long long R, int Cin, int Cout);
 int pcf_hip_linear_backward(const float* dz, const float* x, const float* W, long long R, int Cin, int Cout,
                             float* dx, float* dW, float* db, void* workspace, size_t workspace_bytes, void* stream);

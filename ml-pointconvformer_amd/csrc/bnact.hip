@@ -90,7 +90,7 @@ __global__ __launch_bounds__(FIN_THREADS) void col_finalize_kernel(const float* 
                                                                    float eps, float momentum, float* __restrict__ running_mean,
                                                                    float* __restrict__ running_var, float* __restrict__ o1,
                                                                    float* __restrict__ o2, float* __restrict__ m1,
-                                                                   float* __restrict__ m2) {
+                                                                   float* __restrict__ m2, float* __restrict__ zero_out = nullptr) {
     __shared__ double sa[FIN_THREADS], sb[FIN_THREADS];
     const int c = blockIdx.x * FIN_COLS + (threadIdx.x & (FIN_COLS - 1));
     const int slice = threadIdx.x / FIN_COLS;
@@ -129,6 +129,7 @@ __global__ __launch_bounds__(FIN_THREADS) void col_finalize_kernel(const float* 
                 running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
             }
         } else {
+            if (zero_out) zero_out[c] = 0.f;     // gradient of the bias in front of this batch-statistics BatchNorm
             o1[c] = (float)a;          // dbeta
             o2[c] = (float)b;          // dgamma
             m1[c] = (float)(a / n);
@@ -264,13 +265,13 @@ int pcf_hip_bnact_backward(const float* z, const float* dy, long long R, int C, 
                            const float* gamma, const float* beta, int batch_stats, int act, float* dz, float* dgamma,
                            float* dbeta, void* workspace, size_t workspace_bytes, void* stream) {
     return pcf_hip_bnact_backward_res(z, nullptr, dy, R, C, mean, rstd, gamma, beta, batch_stats, act, dz, nullptr, dgamma,
-                                      dbeta, workspace, workspace_bytes, stream);
+                                      dbeta, nullptr, workspace, workspace_bytes, stream);
 }
 
 int pcf_hip_bnact_backward_res(const float* z, const float* residual, const float* dy, long long R, int C, const float* mean,
                                const float* rstd, const float* gamma, const float* beta, int batch_stats, int act,
-                               float* dz, float* dresidual, float* dgamma, float* dbeta, void* workspace,
-                               size_t workspace_bytes, void* stream) {
+                               float* dz, float* dresidual, float* dgamma, float* dbeta, float* dbias_zero,
+                               void* workspace, size_t workspace_bytes, void* stream) {
     using namespace pcf;
     PCF_REQUIRE(R >= 0 && C >= 1 && act >= 0 && act <= 3, "bnact_backward: bad arguments");
     hipStream_t s = (hipStream_t)stream;
@@ -293,7 +294,7 @@ int pcf_hip_bnact_backward_res(const float* z, const float* residual, const floa
         hipLaunchKernelGGL(col_partials_kernel<1>, dim3(nb), dim3(BLOCK), 0, s, z, dy, R, C, tx_for(C), rpb, mean, rstd, gamma,
                            beta, act, part, residual);
         hipLaunchKernelGGL(col_finalize_kernel<1>, dim3(ceil_div(C, FIN_COLS)), dim3(FIN_THREADS), 0, s, part, nb, R, C, 0.f, 0.f, nullptr,
-                           nullptr, dbeta, dgamma, m1, m2);
+                           nullptr, dbeta, dgamma, m1, m2, batch_stats ? dbias_zero : nullptr);
         if (int e = check_launch("bnact backward reductions")) return e;
         if (!batch_stats) { m1 = nullptr; m2 = nullptr; }
     }

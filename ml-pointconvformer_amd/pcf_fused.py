@@ -332,7 +332,7 @@ _bnact_ws.argtypes = [_LL, _I]
 _bnact_ws.restype = _Z
 _bnact_stats = _sig('pcf_hip_bnact_stats', [_P, _LL, _I, _F, _F, _P, _P, _P, _P, _P, _Z, _P])
 _bnact_fwd = _sig('pcf_hip_bnact_forward_res', [_P, _P, _LL, _I, _P, _P, _P, _P, _I, _P, _P])
-_bnact_bwd = _sig('pcf_hip_bnact_backward_res', [_P, _P, _P, _LL, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _Z, _P])
+_bnact_bwd = _sig('pcf_hip_bnact_backward_res', [_P, _P, _P, _LL, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _Z, _P])
 _linbwd_ws = getattr(_lib, 'pcf_hip_linear_backward_workspace_bytes')
 _linbwd_ws.argtypes = [_LL, _I, _I]
 _linbwd_ws.restype = _Z
@@ -384,6 +384,10 @@ class _WideLinearBNAct(torch.autograd.Function):
         stream = _stream(dev)
         dgamma = torch.empty_like(gamma) if bn else None
         dbeta = torch.empty_like(beta) if bn else None
+        # a bias in front of a batch-statistics BatchNorm has an identically zero gradient (the mean subtraction cancels
+        # it): no column sums of dz; the BN-backward finalize kernel writes the zeros
+        zero_db = bn and training
+        db = torch.empty(Cout, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             if bn or act != ACT_NONE:
                 dz = torch.empty_like(z)
@@ -393,16 +397,12 @@ class _WideLinearBNAct(torch.autograd.Function):
                 ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
                 _call(_bnact_bwd, _ptr(z), _ptr(residual), _ptr(dy), R, Cout, _ptr(mean), _ptr(rstd),
                       _ptr(gamma) if bn else None, _ptr(beta) if bn else None, 1 if training else 0, act, _ptr(dz),
-                      _ptr(dres), _ptr(dgamma), _ptr(dbeta), ws.data_ptr(), nbytes, stream)
+                      _ptr(dres), _ptr(dgamma), _ptr(dbeta), _ptr(db) if zero_db else None, ws.data_ptr(), nbytes, stream)
             else:
                 dz = dy
                 dres = dy if residual is not None else None
             dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
             dW = torch.empty_like(W)
-            # a bias in front of a batch-statistics BatchNorm has an identically zero gradient (the mean subtraction
-            # cancels it): no column sums of dz, exact zeros instead of their rounding noise
-            zero_db = bn and training
-            db = torch.zeros(Cout, dtype=torch.float32, device=dev) if zero_db else torch.empty(Cout, dtype=torch.float32, device=dev)
             nbytes = _linbwd_ws(R, Cin, Cout)
             ws2 = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             _call(_linbwd, _ptr(dz), _ptr(x), _ptr(W), R, Cin, Cout, _ptr(dx), _ptr(dW), None if zero_db else _ptr(db),
