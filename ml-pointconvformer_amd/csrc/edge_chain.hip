@@ -386,7 +386,7 @@ __global__ __launch_bounds__(1024) void chain_finalize_kernel(const FinArgs f) {
 
 extern "C" {
 
-size_t pcf_hip_pcf_chain_workspace_bytes(void) { return (size_t)1024 * 96 * 4 + 1024; }
+size_t pcf_hip_pcf_chain_workspace_bytes(void) { return (size_t)2048 * 96 * 4 + 1024; }
 
 // stats [12][64] floats (device): mean of layer l at stats + l*64, rstd at stats + (6 + l)*64, l in the
 // order mlp_conv, g1, g2, w1, w2, w3.  Training (batch_stats != 0): computed here and the running
@@ -428,7 +428,7 @@ int pcf_hip_pcf_chain_forward(const float* vi, const int64_t* idx, const float* 
         for (int pass = 0; pass < 3; ++pass) {
             int grid;
             if (pass == 0) { grid = chain_grid(E); hipLaunchKernelGGL(pcf_chain_kernel<1>, dim3(grid), dim3(BLOCK), 0, s, a); }
-            else if (pass == 1) { grid = chain_grid(E); hipLaunchKernelGGL(pcf_chain_kernel<2>, dim3(grid), dim3(BLOCK), 0, s, a); }
+            else if (pass == 1) { grid = std::min<long long>(2048, std::max<long long>(1, (E / 16 + NWAVE - 1) / NWAVE)); hipLaunchKernelGGL(pcf_chain_kernel<2>, dim3(grid), dim3(BLOCK), 0, s, a); }
             else if (from_acc) { grid = chain_grid(E); hipLaunchKernelGGL(pcf_chain_tail_kernel<true>, dim3(grid), dim3(BLOCK), 0, s, a); }
             else { grid = chain_grid(E); hipLaunchKernelGGL(pcf_chain_kernel<3>, dim3(grid), dim3(BLOCK), 0, s, a); }
             if (int e = check_launch("pcf_chain pass")) return e;
