@@ -14,12 +14,14 @@
 //     pass 1: sums of g2 and w3                                  (reads the two accumulators, dscore, dw)
 //     pass 2: dz of g2, w3 -> dW of g2, w3;  g = dh1, da2 masked by the ReLU of g1, w2 -> stored (2 x 32 B per
 //             edge) with their sums: the top layers are finished here and never touched again
-//     pass 3: dz of g1, w2 (from the stored g) -> dpe, da1;  sums of mlp_conv and w1 (+ VI)
-//     pass 4: dz of the four lower layers, their dW (outer products on the matrix cores, operands transposed
-//             through LDS) and the gradient of the gathered term u (row-contiguous float atomics; + the
-//             neighbour table)
-// 104 matrix instructions per 16 edges over the four passes instead of 208 with a full recompute; 160-180 B read
-// per edge and pass, 64 B written once.  Bias gradients of a Linear that feeds a training-mode
+//     pass 3: dz of g1, w2 (from the stored g), their dW and the gradient of the gathered term u (row-contiguous
+//             float atomics); g = dpe, da1 masked by the ReLU of mlp_conv, w1 with their sums.  The dz of these
+//             first layers, dz = g.SC + acc.D1 + D0, is LINEAR in what the sums decide (D0, D1), and so is their
+//             dW = sum dz (x) VI = SC.[sum g (x) VI] + D1.[W.(sum VI (x) VI)] + D0.[sum VI]: the pass accumulates
+//             the three bracketed moments (outer products on the matrix cores, operands transposed through LDS),
+//             a one-workgroup kernel combines them once the sums are known.  There is no fourth pass.
+// 84 matrix instructions per 16 edges over the three passes instead of 208 with four full recomputes; 160-190 B
+// read per edge and pass, 64 B written once.  Bias gradients of a Linear that feeds a training-mode
 // BatchNorm are identically zero (the mean subtraction cancels them) and are written as zeros.
 //
 // Matrix-core formulation as in edge_chain.hip (transposed, 16 edges per tile, lane (p = l & 15, g = l >> 4)
@@ -56,7 +58,8 @@ struct ChainBwdArgs {
     float* ga2;                 // [E, 8] da2 * [a2 > 0]
     float* part_top;            // [blocks][2][256] dW tiles of g2 / w3 from pass 2
     float* du;                  // [B*N, 8], zeroed by the host; float atomics
-    float* part;                // pass partials
+    float* part;                // [blocks][NDW][256] dW / moment tiles of pass 3
+    float* part_sums;           // [blocks][96] per-channel sums of the running pass
 };
 
 // constants of slot s, channel c of the tile.  With rs = rstd, x0 = (b - mean) * rs, xhat = acc * rs + x0:
@@ -199,8 +202,8 @@ struct TileIO {
 //   red (LEVEL < 4): groups {L1: g2 | L2: g1 | L3: pe lo, pe hi};   LEVEL 4: dW tiles 0, 1, 3, 4, 6 and du.
 template <int LEVEL>
 __device__ __forceinline__ void guidance_branch(const ChainBwdArgs& a, const float (*cf)[NCONST][16], const float4* wl,
-                                                float* red, float* red_top, float* tb, int* gi, long long t0,
-                                                long long tstride) {
+                                                float* red, float* red_s, float* red_top, float* tb, int* gi,
+                                                long long t0, long long tstride) {
     const ChainArgs& f = a.f;
     const int lane = lane_id(), wave = wave_id(), p = lane & 15, g = lane >> 4;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -247,7 +250,7 @@ __device__ __forceinline__ void guidance_branch(const ChainBwdArgs& a, const flo
         // ---- passes 3, 4: from the stored g of g1 down through the positional encoding ----
         const f32x4 g_h1 = io.load_grad(a.gh1, t, CH);
         const f32x4 x = io.load_x(t);
-        const long long j_cur = LEVEL == 4 ? load_j(t) : -1;
+        const long long j_cur = load_j(t);
         const f32x4 ac_pe0 = mm(wl, 0, lane, x, zero4);
         const f32x4 ac_pe1 = mm(wl, 1, lane, x, zero4);
         const f32x4 y_pe0 = relu4(pre_of(ac_pe0, cf[S_PE0], g));
@@ -260,7 +263,7 @@ __device__ __forceinline__ void guidance_branch(const ChainBwdArgs& a, const flo
             for (int off = 1; off < f.K; off <<= 1) tot += __shfl_xor(tot, off, WAVE);
             if (first) dq[r] -= tot;
         }
-        if (LEVEL == 4) {
+        {
             put_tile(tb + 0 * 16 * TT, dq, p, g);
             put_tile(tb + 1 * 16 * TT, y_pe0, p, g);
             put_tile(tb + 2 * 16 * TT, y_pe1, p, g);
@@ -276,29 +279,34 @@ __device__ __forceinline__ void guidance_branch(const ChainBwdArgs& a, const flo
         }
         const f32x4 g_pe0 = mask_pos(mm(wl, 10, lane, dq, zero4), y_pe0);
         const f32x4 g_pe1 = mask_pos(mm(wl, 11, lane, dq, zero4), y_pe1);
-        if (LEVEL == 3) {
-            s1[0] += g_pe0; s2[0] += g_pe0 * ac_pe0;
-            s1[1] += g_pe1; s2[1] += g_pe1 * ac_pe1;
-        } else {
-            put_tile(tb + 0 * 16 * TT, bn_dz(g_pe0, ac_pe0, cf[S_PE0], g), p, g);
-            put_tile(tb + 1 * 16 * TT, bn_dz(g_pe1, ac_pe1, cf[S_PE1], g), p, g);
-            put_tile(tb + 2 * 16 * TT, x, p, g);
+        s1[0] += g_pe0; s2[0] += g_pe0 * ac_pe0;
+        s1[1] += g_pe1; s2[1] += g_pe1 * ac_pe1;
+        {
+            // moments for the dW of mlp_conv: sum g (x) VI (two tiles) and sum VI' (x) VI' with VI' = (VI, 1)
+            f32x4 x1 = x;
+            if (g == 3) x1[0] = 1.f;                // channel 12 is always padding (cv <= 12)
+            put_tile(tb + 0 * 16 * TT, g_pe0, p, g);
+            put_tile(tb + 1 * 16 * TT, g_pe1, p, g);
+            put_tile(tb + 2 * 16 * TT, x1, p, g);
             accw[0] = outer(tb + 0 * 16 * TT, tb + 2 * 16 * TT, p, g, accw[0]);
             accw[1] = outer(tb + 1 * 16 * TT, tb + 2 * 16 * TT, p, g, accw[1]);
+            accw[4] = outer(tb + 2 * 16 * TT, tb + 2 * 16 * TT, p, g, accw[4]);
         }
     }
-    if (LEVEL == 4) {
-        const int tiles[4] = {0, 1, 3, 4};
+    if (LEVEL == 3) {
+        // tiles: 0, 1 sum g_pe (x) VI' | 3, 4 dW of g1 | 6 sum VI' (x) VI'
+        const int tiles[5] = {0, 1, 3, 4, 6};
         for (int wv = 0; wv < NWAVE; ++wv) {        // wave order: deterministic
             if (wave == wv) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 5; ++i)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) red[tiles[i] * 256 + (4 * g + r) * 16 + p] += accw[i][r];
             }
             __syncthreads();
         }
-    } else {
+    }
+    {
         if (LEVEL == 2) {                           // dW tile of g2 -> red_top[0]
             for (int wv = 0; wv < NWAVE; ++wv) {
                 if (wave == wv) {
@@ -309,7 +317,7 @@ __device__ __forceinline__ void guidance_branch(const ChainBwdArgs& a, const flo
             }
         }
         // L1: g2 -> group 0.  L2: g1 -> group 0.  L3: pe lo, pe hi -> groups 0, 1.
-        float (*rw)[3][2][16] = reinterpret_cast<float (*)[3][2][16]>(red);
+        float (*rw)[3][2][16] = reinterpret_cast<float (*)[3][2][16]>(red_s);
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -326,7 +334,8 @@ __device__ __forceinline__ void guidance_branch(const ChainBwdArgs& a, const flo
 //   red (LEVEL < 4): groups {L1: w3 -> 1 | L2: w2 -> 1 | L3: w1 -> 2};   LEVEL 4: dW tiles 2, 5, 7.
 template <int LEVEL>
 __device__ __forceinline__ void weightnet_branch(const ChainBwdArgs& a, const float (*cf)[NCONST][16], const float4* wl,
-                                                 float* red, float* red_top, float* tb, long long t0, long long tstride) {
+                                                 float* red, float* red_s, float* red_top, float* tb, long long t0,
+                                                 long long tstride) {
     const ChainArgs& f = a.f;
     const int lane = lane_id(), wave = wave_id(), p = lane & 15, g = lane >> 4;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -362,22 +371,23 @@ __device__ __forceinline__ void weightnet_branch(const ChainBwdArgs& a, const fl
         const f32x4 ac_a1 = mm(wl, 2, lane, x, zero4);
         const f32x4 y_a1 = relu4(pre_of(ac_a1, cf[S_W1], g));
         const f32x4 dz_a2 = bn_dz(g_a2, ac_a2, cf[S_W2], g);
-        if (LEVEL == 4) {
+        {
             put_tile(tb + 0 * 16 * TT, dz_a2, p, g);
             put_tile(tb + 1 * 16 * TT, y_a1, p, g);
             accw[1] = outer(tb + 0 * 16 * TT, tb + 1 * 16 * TT, p, g, accw[1]);
         }
         const f32x4 g_a1 = mask_pos(mm(wl, 12, lane, dz_a2, zero4), y_a1);
-        if (LEVEL == 3) {
-            s1 += g_a1; s2 += g_a1 * ac_a1;
-        } else {
-            put_tile(tb + 0 * 16 * TT, bn_dz(g_a1, ac_a1, cf[S_W1], g), p, g);
-            put_tile(tb + 1 * 16 * TT, x, p, g);
+        s1 += g_a1; s2 += g_a1 * ac_a1;
+        {   // moment for the dW of w1: sum g (x) VI' (the guidance workgroups accumulate sum VI' (x) VI')
+            f32x4 x1 = x;
+            if (g == 3) x1[0] = 1.f;
+            put_tile(tb + 0 * 16 * TT, g_a1, p, g);
+            put_tile(tb + 1 * 16 * TT, x1, p, g);
             accw[0] = outer(tb + 0 * 16 * TT, tb + 1 * 16 * TT, p, g, accw[0]);
         }
     }
-    if (LEVEL == 4) {
-        const int tiles[2] = {2, 5};
+    if (LEVEL == 3) {
+        const int tiles[2] = {2, 5};            // 2: sum g_a1 (x) VI' | 5: dW of w2
         for (int wv = 0; wv < NWAVE; ++wv) {
             if (wave == wv) {
 #pragma unroll
@@ -387,7 +397,8 @@ __device__ __forceinline__ void weightnet_branch(const ChainBwdArgs& a, const fl
             }
             __syncthreads();
         }
-    } else {
+    }
+    {
         if (LEVEL == 2) {                           // dW tile of w3 -> red_top[1]
             for (int wv = 0; wv < NWAVE; ++wv) {
                 if (wave == wv) {
@@ -397,7 +408,7 @@ __device__ __forceinline__ void weightnet_branch(const ChainBwdArgs& a, const fl
                 __syncthreads();
             }
         }
-        float (*rw)[3][2][16] = reinterpret_cast<float (*)[3][2][16]>(red);
+        float (*rw)[3][2][16] = reinterpret_cast<float (*)[3][2][16]>(red_s);
         const int q = LEVEL == 3 ? 2 : 1;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -421,47 +432,51 @@ template <int NG> __host__ inline int branch_blocks(int grid, bool guidance) {  
 // matrix instructions per tile, guidance : WeightNet = 4 : 4 (pass 1), 12 : 12 (pass 2), 16 : 8 (pass 3), 32 : 16 (pass 4).
 // Measured: passes 1-3 do not care between 4 and 6 of 8 (they are closer to the memory side); pass 4 is 8 % faster
 // with 6 of 8 than with 5.
-template <int LEVEL> struct SplitOf { static constexpr int NG = LEVEL == 4 ? 6 : 5; };
+template <int LEVEL> struct SplitOf { static constexpr int NG = LEVEL == 3 ? 6 : 5; };
 
 template <int LEVEL>
 __global__ __launch_bounds__(BLOCK) void pcf_chain_bwd_kernel(const ChainBwdArgs a, int grid8) {
     __shared__ __align__(16) float cf[NSLOT][NCONST][16];
     __shared__ float4 wl[NFRAG * WAVE];
-    __shared__ float red[LEVEL == 4 ? NDW * 256 : NWAVE * 96];
+    __shared__ float red[LEVEL == 3 ? NDW * 256 : 1];          // dW / moment tiles of the last pass
+    __shared__ float red_s[NWAVE * 96];                         // per-channel sums of the pass
     __shared__ float red_top[LEVEL == 2 ? 2 * 256 : 1];
-    __shared__ __align__(16) float tbuf[LEVEL == 4 ? NWAVE * 3 * 16 * TT : (LEVEL == 2 ? NWAVE * 2 * 16 * TT : 4)];
+    __shared__ __align__(16) float tbuf[LEVEL == 3 ? NWAVE * 3 * 16 * TT : (LEVEL == 2 ? NWAVE * 2 * 16 * TT : 4)];
     __shared__ int gi[NWAVE][16];
     stage_consts(a, cf, LEVEL);
     stage_weights(a, wl);
-    for (int t = threadIdx.x; t < (LEVEL == 4 ? NDW * 256 : NWAVE * 96); t += BLOCK) red[t] = 0.f;
+    for (int t = threadIdx.x; t < NWAVE * 96; t += BLOCK) red_s[t] = 0.f;
+    if (LEVEL == 3)
+        for (int t = threadIdx.x; t < NDW * 256; t += BLOCK) red[t] = 0.f;
     if (LEVEL == 2)
         for (int t = threadIdx.x; t < 2 * 256; t += BLOCK) red_top[t] = 0.f;
     __syncthreads();
     const int wave = wave_id();
-    float* tb = LEVEL == 4 ? tbuf + wave * 3 * 16 * TT : (LEVEL == 2 ? tbuf + wave * 2 * 16 * TT : tbuf);
+    float* tb = LEVEL == 3 ? tbuf + wave * 3 * 16 * TT : (LEVEL == 2 ? tbuf + wave * 2 * 16 * TT : tbuf);
     constexpr int NG = SplitOf<LEVEL>::NG;
     const int rank = branch_rank<NG>(blockIdx.x);
     if (is_guidance_block<NG>(blockIdx.x))
-        guidance_branch<LEVEL>(a, cf, wl, red, red_top, tb, gi[wave], (long long)rank * NWAVE + wave, (long long)grid8 * NG * NWAVE);
+        guidance_branch<LEVEL>(a, cf, wl, red, red_s, red_top, tb, gi[wave], (long long)rank * NWAVE + wave,
+                               (long long)grid8 * NG * NWAVE);
     else
-        weightnet_branch<LEVEL>(a, cf, wl, red, red_top, tb, (long long)rank * NWAVE + wave, (long long)grid8 * (8 - NG) * NWAVE);
-    if (LEVEL == 4) {
+        weightnet_branch<LEVEL>(a, cf, wl, red, red_s, red_top, tb, (long long)rank * NWAVE + wave,
+                                (long long)grid8 * (8 - NG) * NWAVE);
+    __syncthreads();
+    if (LEVEL == 3) {
         float* outp = a.part + (size_t)blockIdx.x * (NDW * 256);
         for (int u = threadIdx.x; u < NDW * 256; u += BLOCK) outp[u] = red[u];
-        return;
     }
-    __syncthreads();
     if (LEVEL == 2) {
         float* outp = a.part_top + (size_t)blockIdx.x * 512;
         for (int u = threadIdx.x; u < 512; u += BLOCK) outp[u] = red_top[u];
     }
     if (threadIdx.x < 96) {
-        const float (*rw)[3][2][16] = reinterpret_cast<const float (*)[3][2][16]>(red);
+        const float (*rw)[3][2][16] = reinterpret_cast<const float (*)[3][2][16]>(red_s);
         const int q = threadIdx.x / 32, which = (threadIdx.x >> 4) & 1, c = threadIdx.x & 15;
         float tsum = 0.f;
 #pragma unroll
         for (int w = 0; w < NWAVE; ++w) tsum += rw[w][q][which][c];
-        a.part[(size_t)blockIdx.x * 96 + threadIdx.x] = tsum;
+        a.part_sums[(size_t)blockIdx.x * 96 + threadIdx.x] = tsum;
     }
 }
 
@@ -505,53 +520,118 @@ __global__ __launch_bounds__(1024) void chain_bwd_finalize_kernel(const BwdFinAr
     }
 }
 
-// dW of the six layers from the per-workgroup 16x16 tiles of pass 4; one workgroup per 64 tile elements,
-// 16 slices of the partial list each (fixed order).
-struct BwdParamArgs {
-    const float* part; const float* part_top; int nblocks;
-    float* dW[6];
-    float* db[6];               // written as zeros (bias in front of a training-mode BatchNorm)
-    int cv, g, heads, cm;
-};
+// After pass 3: (1) fixed-order reduction of the per-workgroup tiles and sums into a small buffer,
+//   red[0 .. 7*256)    tiles of pass 3: 0, 1 sum g_pe (x) VI' | 2 sum g_a1 (x) VI' | 3, 4 dW g1 | 5 dW w2 | 6 sum VI' (x) VI'
+//   red[7*256 .. 9*256) tiles of pass 2: dW g2, dW w3
+//   red[9*256 .. +96)   sums of pass 3: (sum g, sum g.acc) of mlp_conv lo / hi and w1
+// (2) one workgroup turns them into the six dW, the dgamma / dbeta of mlp_conv and w1 and the zero db.
+constexpr int RED_TILES = 9 * 256;
+constexpr int RED_TOTAL = RED_TILES + 96;
 
-__global__ __launch_bounds__(1024) void chain_bwd_params_kernel(const BwdParamArgs f) {
+struct BwdReduceArgs { const float* part; const float* part_top; const float* part_sums; int nblocks; float* red; };
+
+__global__ __launch_bounds__(1024) void chain_bwd_reduce_kernel(const BwdReduceArgs f) {
     __shared__ float sh[16][64];
-    const int e = blockIdx.x * 64 + (threadIdx.x & 63);        // element of the [NDW][16][16] tile set
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63);
     const int slice = threadIdx.x >> 6;
-    // tiles 6, 7 (g2, w3) were accumulated by pass 2 (part_top, 2 tiles per workgroup), the rest by pass 4
-    const bool top = (e >> 8) >= 6;
-    const float* src = top ? f.part_top + (e - 6 * 256) : f.part + e;
-    const size_t stride = top ? 512 : NDW * 256;
+    const float* src = nullptr;
+    size_t stride = 0;
+    if (e < 7 * 256) { src = f.part + e; stride = NDW * 256; }
+    else if (e < RED_TILES) { src = f.part_top + (e - 7 * 256); stride = 512; }
+    else if (e < RED_TOTAL) { src = f.part_sums + (e - RED_TILES); stride = 96; }
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int p = slice;
-    for (; p + 48 < f.nblocks; p += 64) {
-        a0 += src[(size_t)p * stride];
-        a1 += src[(size_t)(p + 16) * stride];
-        a2 += src[(size_t)(p + 32) * stride];
-        a3 += src[(size_t)(p + 48) * stride];
+    if (src) {
+        int p = slice;
+        for (; p + 48 < f.nblocks; p += 64) {
+            a0 += src[(size_t)p * stride];
+            a1 += src[(size_t)(p + 16) * stride];
+            a2 += src[(size_t)(p + 32) * stride];
+            a3 += src[(size_t)(p + 48) * stride];
+        }
+        for (; p < f.nblocks; p += 16) a0 += src[(size_t)p * stride];
     }
-    for (; p < f.nblocks; p += 16) a0 += src[(size_t)p * stride];
     sh[slice][threadIdx.x & 63] = (a0 + a1) + (a2 + a3);
     __syncthreads();
-    if (blockIdx.x == 0 && threadIdx.x >= 64 && threadIdx.x < 64 + 6 * 32) {
-        const int l = (threadIdx.x - 64) >> 5, o = (threadIdx.x - 64) & 31;
-        const int couts[6] = {f.g, CH, f.heads, CH, CH, f.cm};
-        if (o < couts[l]) f.db[l][o] = 0.f;
-    }
-    if (threadIdx.x >= 64) return;
+    if (threadIdx.x >= 64 || !src) return;
     float tot = 0.f;
 #pragma unroll
     for (int sl = 0; sl < 16; ++sl) tot += sh[sl][threadIdx.x];
-    const int tile = e >> 8, o = (e >> 4) & 15, c = e & 15;
-    switch (tile) {
-        case 0: if (o < f.g && c < f.cv) f.dW[L_PE][o * f.cv + c] = tot; break;
-        case 1: if (16 + o < f.g && c < f.cv) f.dW[L_PE][(16 + o) * f.cv + c] = tot; break;
-        case 2: if (o < CH && c < f.cv) f.dW[L_W1][o * f.cv + c] = tot; break;
-        case 3: if (o < CH && c < f.g) f.dW[L_G1][o * f.g + c] = tot; break;
-        case 4: if (o < CH && 16 + c < f.g) f.dW[L_G1][o * f.g + 16 + c] = tot; break;
-        case 5: if (o < CH && c < CH) f.dW[L_W2][o * CH + c] = tot; break;
-        case 6: if (o < f.heads && c < CH) f.dW[L_G2][o * CH + c] = tot; break;
-        default: if (o < f.cm && c < CH) f.dW[L_W3][o * CH + c] = tot; break;
+    f.red[e] = tot;
+}
+
+struct BwdCombineArgs {
+    const float* red;
+    const float* W_pe; const float* W_w1;            // [g, cv], [8, cv]
+    const float* stats;                              // forward statistics: mean at l*64, rstd at (6+l)*64
+    const float* b_pe; const float* b_w1; const float* gamma_pe; const float* gamma_w1;
+    float* dW[6]; float* db[6];
+    float* dgamma_pe; float* dbeta_pe; float* dgamma_w1; float* dbeta_w1;
+    long long R;
+    int cv, g, heads, cm;
+};
+
+__global__ __launch_bounds__(BLOCK) void chain_bwd_combine_kernel(const BwdCombineArgs f) {
+    __shared__ float sc[48], d0[48], d1[48];         // mlp_conv channels 0..31, w1 channels 32..39
+    const float* red = f.red;
+    const int tid = threadIdx.x;
+    if (tid < 40) {
+        const bool pe = tid < 32;
+        const int o = pe ? tid : tid - 32;
+        const int layer = pe ? L_PE : L_W1;
+        const bool valid = pe ? o < f.g : true;
+        float vsc = 0.f, vd0 = 0.f, vd1 = 0.f;
+        if (valid) {
+            // sums live in groups: mlp_conv lo -> group 0, hi -> group 1, w1 -> group 2; [group][sum | sum g.acc][16]
+            const int grp = pe ? (o >> 4) : 2, c = pe ? (o & 15) : o;
+            const double S1 = (double)red[RED_TILES + grp * 32 + c], S2 = (double)red[RED_TILES + grp * 32 + 16 + c];
+            const double rs = (double)f.stats[(6 + layer) * 64 + o];
+            const double bias = (double)(pe ? f.b_pe[o] : f.b_w1[o]);
+            const double x0 = (bias - (double)f.stats[layer * 64 + o]) * rs;
+            const double gamma = (double)(pe ? f.gamma_pe[o] : f.gamma_w1[o]);
+            const double dgamma = rs * S2 + x0 * S1;                       // sum g * xhat
+            (pe ? f.dbeta_pe : f.dbeta_w1)[o] = (float)S1;
+            (pe ? f.dgamma_pe : f.dgamma_w1)[o] = (float)dgamma;
+            const double gm = S1 / (double)f.R, gxm = dgamma / (double)f.R;
+            const double s = rs * gamma;
+            vsc = (float)s;
+            vd1 = (float)(-s * gxm * rs);
+            vd0 = (float)(-s * (gm + gxm * x0));
+        }
+        sc[tid] = vsc; d0[tid] = vd0; d1[tid] = vd1;
+    }
+    // zero bias gradients (bias in front of a training-mode BatchNorm)
+    if (tid >= 64 && tid < 64 + 6 * 32) {
+        const int l = (tid - 64) >> 5, o = (tid - 64) & 31;
+        const int couts[6] = {f.g, CH, f.heads, CH, CH, f.cm};
+        if (o < couts[l]) f.db[l][o] = 0.f;
+    }
+    __syncthreads();
+    const float* XX = red + 6 * 256;                 // [c'][c] = sum VI'[c'] VI'[c], VI'[12] = 1
+    // dW of mlp_conv and w1: SC * M1 + D1 * (W . XX) + D0 * sum VI
+    for (int e = tid; e < 40 * 16; e += BLOCK) {
+        const int row = e >> 4, c = e & 15;           // row: 0..31 mlp_conv, 32..39 w1
+        const bool pe = row < 32;
+        const int o = pe ? row : row - 32;
+        if (c >= f.cv || (pe && o >= f.g)) continue;
+        const float* W = pe ? f.W_pe : f.W_w1;
+        const float M1 = pe ? red[(o >> 4) * 256 + (o & 15) * 16 + c] : red[2 * 256 + o * 16 + c];
+        float M2 = 0.f;
+        for (int k = 0; k < f.cv; ++k) M2 += W[o * f.cv + k] * XX[k * 16 + c];
+        const float M3 = XX[12 * 16 + c];
+        const float v = sc[row] * M1 + d1[row] * M2 + d0[row] * M3;
+        (pe ? f.dW[L_PE] : f.dW[L_W1])[o * f.cv + c] = v;
+    }
+    // the four upper layers: tiles are the gradients themselves
+    for (int e = tid; e < 5 * 256; e += BLOCK) {
+        const int t = e >> 8, o = (e >> 4) & 15, c = e & 15;
+        const float v = red[(t < 3 ? 3 + t : 4 + t) * 256 + o * 16 + c];      // t: 0 g1 lo, 1 g1 hi, 2 w2, 3 g2, 4 w3
+        switch (t) {
+            case 0: if (o < CH && c < f.g) f.dW[L_G1][o * f.g + c] = v; break;
+            case 1: if (o < CH && 16 + c < f.g) f.dW[L_G1][o * f.g + 16 + c] = v; break;
+            case 2: if (o < CH && c < CH) f.dW[L_W2][o * CH + c] = v; break;
+            case 3: if (o < f.heads && c < CH) f.dW[L_G2][o * CH + c] = v; break;
+            default: if (o < f.cm && c < CH) f.dW[L_W3][o * CH + c] = v; break;
+        }
     }
 }
 
@@ -562,7 +642,8 @@ extern "C" {
 size_t pcf_hip_pcf_chain_backward_workspace_bytes(long long E) {
     // per-workgroup partials of passes 1-4, the 12 x 64 per-channel means, and the two [E, 8] gradients pass 2 hands
     // to passes 3-4
-    return ((size_t)1024 * pcf::NDW * 256 + (size_t)1024 * 512 + 12 * 64) * 4 + (size_t)(E > 0 ? E : 0) * 2 * pcf::CH * 4 + 1024;
+    return ((size_t)1024 * pcf::NDW * 256 + (size_t)1024 * 512 + (size_t)1024 * 96 + 4096 + 12 * 64) * 4 +
+           (size_t)(E > 0 ? E : 0) * 2 * pcf::CH * 4 + 1024;
 }
 
 int pcf_hip_pcf_chain_backward(const float* vi, const int64_t* idx, const float* h1_acc, const float* a2_acc,
@@ -608,7 +689,9 @@ int pcf_hip_pcf_chain_backward(const float* vi, const int64_t* idx, const float*
     float* means = static_cast<float*>(workspace);           // [12][64]: mean g, then mean g*xhat, per layer
     a.part = means + 12 * 64;
     a.part_top = a.part + (size_t)1024 * NDW * 256;
-    a.gh1 = a.part_top + (size_t)1024 * 512;           // 16-byte aligned: every region is a multiple of 64 floats
+    a.part_sums = a.part_top + (size_t)1024 * 512;
+    float* redbuf = a.part_sums + (size_t)1024 * 96;   // RED_TOTAL <= 4096 floats
+    a.gh1 = redbuf + 4096;                             // 16-byte aligned: every region is a multiple of 64 floats
     a.ga2 = a.gh1 + (size_t)E * CH;
     for (int l = 0; l < 6; ++l) {
         a.f.W[l] = W[l]; a.f.b[l] = b[l]; a.f.gamma[l] = gamma[l]; a.f.beta[l] = beta[l];
@@ -618,33 +701,36 @@ int pcf_hip_pcf_chain_backward(const float* vi, const int64_t* idx, const float*
     a.dscore = dscore; a.dw = dw; a.du = du; a.h1_acc = h1_acc; a.a2_acc = a2_acc;
     // both branches need at least one workgroup; a multiple of 8 keeps the 5 : 3 split exact
     const int grid = std::max(8, (chain_grid(E) + 7) / 8 * 8);
-    for (int pass = 0; pass < 3; ++pass) {
+    for (int pass = 0; pass < 2; ++pass) {
         if (pass == 0) hipLaunchKernelGGL(pcf_chain_bwd_kernel<1>, dim3(grid), dim3(BLOCK), 0, s, a, grid / 8);
-        else if (pass == 1) hipLaunchKernelGGL(pcf_chain_bwd_kernel<2>, dim3(grid), dim3(BLOCK), 0, s, a, grid / 8);
-        else hipLaunchKernelGGL(pcf_chain_bwd_kernel<3>, dim3(grid), dim3(BLOCK), 0, s, a, grid / 8);
+        else hipLaunchKernelGGL(pcf_chain_bwd_kernel<2>, dim3(grid), dim3(BLOCK), 0, s, a, grid / 8);
         if (int e = check_launch("pcf_chain_backward pass")) return e;
         BwdFinArgs fa{};
-        fa.part = a.part; fa.nblocks = grid; fa.R = E;
+        fa.part = a.part_sums; fa.nblocks = grid; fa.R = E;
         auto set = [&](int q, int layer, int chan0, int count) {
             fa.g[q].dbeta = dbeta[layer]; fa.g[q].dgamma = dgamma[layer];
             fa.g[q].gmean = means + layer * 64; fa.g[q].gxmean = means + (6 + layer) * 64;
             fa.g[q].mean = stats + layer * 64; fa.g[q].rstd = stats + (6 + layer) * 64; fa.g[q].bias = b[layer];
             fa.g[q].chan0 = chan0; fa.g[q].count = count;
         };
+        // (guidance workgroups fill group 0, WeightNet workgroups group 1; the rest are zeros)
         if (pass == 0) { set(0, L_G2, 0, heads); set(1, L_W3, 0, cm); }
-        else if (pass == 1) { set(0, L_G1, 0, CH); set(1, L_W2, 0, CH); }
-        else { set(0, L_PE, 0, std::min(g, 16)); set(1, L_PE, 16, std::max(g - 16, 0)); set(2, L_W1, 0, CH); }
-        // (guidance workgroups fill groups 0 [and 1 in pass 3], WeightNet workgroups group 1 [2 in pass 3]; the rest are zeros)
+        else { set(0, L_G1, 0, CH); set(1, L_W2, 0, CH); }
         hipLaunchKernelGGL(chain_bwd_finalize_kernel, dim3(3), dim3(1024), 0, s, fa);
         if (int e = check_launch("pcf_chain_backward finalize")) return e;
     }
-    hipLaunchKernelGGL(pcf_chain_bwd_kernel<4>, dim3(grid), dim3(BLOCK), 0, s, a, grid / 8);
+    hipLaunchKernelGGL(pcf_chain_bwd_kernel<3>, dim3(grid), dim3(BLOCK), 0, s, a, grid / 8);
     if (int e = check_launch("pcf_chain_backward final pass")) return e;
-    BwdParamArgs pa{};
-    pa.part = a.part; pa.part_top = a.part_top; pa.nblocks = grid; pa.cv = cv; pa.g = g; pa.heads = heads; pa.cm = cm;
-    for (int l = 0; l < 6; ++l) { pa.dW[l] = dW[l]; pa.db[l] = db[l]; }
-    hipLaunchKernelGGL(chain_bwd_params_kernel, dim3(NDW * 256 / 64), dim3(1024), 0, s, pa);
-    return check_launch("pcf_chain_backward parameter reduction");
+    BwdReduceArgs ra{a.part, a.part_top, a.part_sums, grid, redbuf};
+    hipLaunchKernelGGL(chain_bwd_reduce_kernel, dim3((RED_TOTAL + 63) / 64), dim3(1024), 0, s, ra);
+    BwdCombineArgs ca{};
+    ca.red = redbuf; ca.W_pe = W[L_PE]; ca.W_w1 = W[L_W1]; ca.stats = stats;
+    ca.b_pe = b[L_PE]; ca.b_w1 = b[L_W1]; ca.gamma_pe = gamma[L_PE]; ca.gamma_w1 = gamma[L_W1];
+    for (int l = 0; l < 6; ++l) { ca.dW[l] = dW[l]; ca.db[l] = db[l]; }
+    ca.dgamma_pe = dgamma[L_PE]; ca.dbeta_pe = dbeta[L_PE]; ca.dgamma_w1 = dgamma[L_W1]; ca.dbeta_w1 = dbeta[L_W1];
+    ca.R = E; ca.cv = cv; ca.g = g; ca.heads = heads; ca.cm = cm;
+    hipLaunchKernelGGL(chain_bwd_combine_kernel, dim3(1), dim3(BLOCK), 0, s, ca);
+    return check_launch("pcf_chain_backward parameter gradients");
 }
 
 }  // extern "C"
