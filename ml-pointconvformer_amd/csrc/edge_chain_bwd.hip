@@ -434,8 +434,9 @@ template <int NG> __host__ inline int branch_blocks(int grid, bool guidance) {  
 // with 6 of 8 than with 5.
 template <int LEVEL> struct SplitOf { static constexpr int NG = LEVEL == 3 ? 6 : 5; };
 
+// at least 4 waves per SIMD (<= 128 VGPRs): the last pass lands on 132 without the bound and runs 196 us instead of 147
 template <int LEVEL>
-__global__ __launch_bounds__(BLOCK) void pcf_chain_bwd_kernel(const ChainBwdArgs a, int grid8) {
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) void pcf_chain_bwd_kernel(const ChainBwdArgs a, int grid8) {
     __shared__ __align__(16) float cf[NSLOT][NCONST][16];
     __shared__ float4 wl[NFRAG * WAVE];
     __shared__ float red[LEVEL == 3 ? NDW * 256 : 1];          // dW / moment tiles of the last pass
