@@ -341,28 +341,29 @@ struct FinGroup { float* mean; float* rstd; float* running_mean; float* running_
 struct FinArgs { FinGroup g[3]; const float* part; int nblocks; long long R; float eps; float momentum; };
 
 __global__ __launch_bounds__(1024) void chain_finalize_kernel(const FinArgs f) {
-    // one workgroup per group: 32 values (sum, sum of squares of 16 channels) x 32 slices of the partial list,
-    // two independent fp64 chains per slice (a single 1024-thread workgroup over all 96 values took 12 us)
-    __shared__ double sh[32][32];
-    const int gq = blockIdx.x;
-    const int v = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    // 12 workgroups: (group, quarter of its 16 channels); 8 values (sum | second sum of 4 channels) x 128 slices of
+    // the partial list each, so a slice walks 8-16 partials (3 workgroups x 32 slices took 8-10 us)
+    __shared__ double sh[128][8];
+    const int gq = blockIdx.x >> 2, quarter = blockIdx.x & 3;
+    const int v = threadIdx.x & 7, slice = threadIdx.x >> 3;
+    const int col = (v >> 2) * 16 + quarter * 4 + (v & 3);          // which * 16 + channel
     {
         double a0 = 0.0, a1 = 0.0;
         int p = slice;
-        for (; p + 32 < f.nblocks; p += 64) {
-            a0 += (double)f.part[(size_t)p * 96 + gq * 32 + v];
-            a1 += (double)f.part[(size_t)(p + 32) * 96 + gq * 32 + v];
+        for (; p + 128 < f.nblocks; p += 256) {
+            a0 += (double)f.part[(size_t)p * 96 + gq * 32 + col];
+            a1 += (double)f.part[(size_t)(p + 128) * 96 + gq * 32 + col];
         }
-        if (p < f.nblocks) a0 += (double)f.part[(size_t)p * 96 + gq * 32 + v];
+        if (p < f.nblocks) a0 += (double)f.part[(size_t)p * 96 + gq * 32 + col];
         sh[slice][v] = a0 + a1;
     }
     __syncthreads();
-    if (threadIdx.x < 16) {
-        const int gi = gq, c = threadIdx.x;
+    if (threadIdx.x < 4) {
+        const int gi = gq, c = quarter * 4 + threadIdx.x;
         double sums[2] = {0.0, 0.0};
 #pragma unroll
         for (int which = 0; which < 2; ++which)
-            for (int sl = 0; sl < 32; ++sl) sums[which] += sh[sl][which * 16 + c];
+            for (int sl = 0; sl < 128; ++sl) sums[which] += sh[sl][which * 4 + threadIdx.x];
         const FinGroup& g = f.g[gi];
         if (g.mean && c < g.count) {
             const int o = g.chan0 + c;
@@ -443,7 +444,7 @@ int pcf_hip_pcf_chain_forward(const float* vi, const int64_t* idx, const float* 
             if (pass == 0) { set(0, L_PE, 0, std::min(g, 16)); set(1, L_PE, 16, std::max(g - 16, 0)); set(2, L_W1, 0, CH); }
             else if (pass == 1) { set(0, L_G1, 0, CH); set(1, L_W2, 0, CH); }
             else { set(0, L_G2, 0, heads); set(1, L_W3, 0, cm); }
-            hipLaunchKernelGGL(chain_finalize_kernel, dim3(3), dim3(1024), 0, s, f);
+            hipLaunchKernelGGL(chain_finalize_kernel, dim3(12), dim3(1024), 0, s, f);
             if (int e = check_launch("pcf_chain finalize")) return e;
         }
     }
