@@ -264,7 +264,7 @@ int pcf_hip_guidance_diff_backward(const float* ds, const int64_t* idx, const ui
  * K a power of two <= 16 and E % 16 == 0 (PCF_E_UNSUPPORTED otherwise: callers fall back to the
  * layer-at-a-time entry points above).
  * stats [12][64] floats on the device: mean of layer l at stats + 64*l, 1/sqrt(var+eps) at stats + 64*(6+l).
- * forward, batch_stats != 0: statistics are computed (four recompute passes), written to stats and folded into
+ * forward, batch_stats != 0: statistics are computed (four passes: the first two from vi, the last two from the stored accumulators), written to stats and folded into
  * the running statistics (nullable); batch_stats == 0: the caller provides them and only score / w are produced.
  * pe, a1, h1, a2 (nullable) receive the intermediate activations [E, g], [E, 8], [E, 8], [E, 8] (for the
  * layer-at-a-time backward); h1_acc, a2_acc (nullable) the raw 8-channel accumulators of g1 and w2 (pre-BatchNorm,
@@ -279,8 +279,9 @@ int pcf_hip_pcf_chain_forward(const float* vi, const int64_t* idx, const float* 
                               void* stream);
 /* Adjoint of the training-mode forward given dscore [E, heads], dw [E, cm] (from pcf_hip_pcf_backward), the
  * stats and the h1_acc / a2_acc of the forward: du [B*N, 8] (zeroed here, float atomics) and, per layer, dW, db,
- * dgamma, dbeta.  Four passes; the top layers are recomputed from the two stored accumulators, the first layers
- * from vi; nothing per-edge is written.  db is written as zeros (a bias in front of a training-mode BatchNorm has
+ * dgamma, dbeta.  Three passes: the top layers are recomputed from the two stored accumulators, the first layers
+ * from vi, their weight gradients from moments that are linear in the BatchNorm sums; 64 B per edge of masked
+ * gradients go through the workspace.  db is written as zeros (a bias in front of a training-mode BatchNorm has
  * an identically zero gradient). */
 size_t pcf_hip_pcf_chain_backward_workspace_bytes(long long E);
 int pcf_hip_pcf_chain_backward(const float* vi, const int64_t* idx, const float* h1_acc, const float* a2_acc,

@@ -503,7 +503,7 @@ class _PCFChain(torch.autograd.Function):
         w = torch.empty(B, M, K, cm, **f32)
         pe = a1 = h1 = a2 = h1_acc = a2_acc = None
         if training:
-            if fused_backward:          # the four-pass backward restarts from the raw accumulators of g1 and w2
+            if fused_backward:          # the fused backward restarts from the raw accumulators of g1 and w2
                 h1_acc, a2_acc = torch.empty(B, M, K, 8, **f32), torch.empty(B, M, K, 8, **f32)
             else:                       # the layer-at-a-time backward reads the intermediate activations
                 pe, a1 = torch.empty(B, M, K, g, **f32), torch.empty(B, M, K, 8, **f32)
@@ -593,7 +593,7 @@ def pcf_chain_supported(cv, g, heads, cm, K, hidden_ok, n_edges, edges_per_batch
 
 def pcf_chain(vi, idx, u, fx, layers, training, fused_backward=True, g1_positional_weight=None):
     """layers: six (nn.Linear, nn.BatchNorm1d) pairs in the order mlp_conv, g1, g2, w1, w2, w3; the g1 weight is
-    split here (its gathered half already went into `u`).  fused_backward: adjoint through the four-pass
+    split here (its gathered half already went into `u`).  fused_backward: adjoint through the three-pass
     recompute kernel (csrc/edge_chain_bwd.hip); False keeps the activations and goes layer by layer."""
     _floats(vi=vi, u=u, fx=fx)
     _check_input(idx, 'nei_inds', torch.int64)

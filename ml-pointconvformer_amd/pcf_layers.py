@@ -356,7 +356,7 @@ class PCFLayer(pcf_fused.CounterScope):
         guidance_x = self.guidance_unary(feats_x)
         chain = self._chain_layers(wn_in, nei_inds) if not strided else None
         if chain is not None:
-            # self neighbourhoods, BatchNorm everywhere: the whole edge graph in four fused passes
+            # self neighbourhoods, BatchNorm everywhere: the whole edge graph in four fused passes forward, three backward
             g1 = self.guidance_weight.mlp[0].c
             G = guidance_x.shape[-1]
             Wa, Wb = pcf_fused.split_columns(g1.weight, G)      # gathered half | positional half

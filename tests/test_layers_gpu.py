@@ -84,7 +84,7 @@ def _run(layer, g, device, feat_keys, order, opt=False):
 PCF_ORDER = ['dense_xyz', 'dense_feats', 'nei_inds', 'dense_xyz_norm', 'sparse_xyz', 'sparse_xyz_norm']
 
 
-# edge graph: fused forward + fused four-pass backward (default) / fused forward + layer-at-a-time backward /
+# edge graph: fused forward + fused three-pass backward (default) / fused forward + layer-at-a-time backward /
 # every layer through its own kernels
 CHAIN_MODES = {'fused': {}, 'layerwise_bwd': dict(EDGE_CHAIN_LAYERWISE_BACKWARD=True), 'off': dict(NO_EDGE_CHAIN=True)}
 
@@ -104,7 +104,7 @@ def test_pcf_layer_matches_reference(device, name, ci, co, cm, heads, mode):
 @pytest.mark.parametrize('B,N,K,cm,heads,gfl', [(2, 3000, 16, 16, 8, 32), (1, 4096, 8, 8, 4, 16), (3, 1000, 4, 16, 8, 20),
                                                 (4, 1001, 4, 4, 2, 8), (1, 64, 2, 16, 8, 32)])
 def test_fused_edge_chain_backward_against_layerwise(device, B, N, K, cm, heads, gfl):
-    """The four-pass recompute backward (edge_chain_bwd.hip) against the layer-at-a-time kernels on a random
+    """The fused recompute backward (edge_chain_bwd.hip) against the layer-at-a-time kernels on a random
     layer: same forward, gradients of the features, of the per-point guidance term and of all 24 parameters."""
     import pcf_layers
     torch.manual_seed(5)
