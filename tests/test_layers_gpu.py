@@ -528,6 +528,43 @@ def test_edge_geometry_store_paths(device, B, M, K):
         torch.testing.assert_close(vi.cpu(), O.vi_features(wrel, O.gather_rows(nrm, idx), cnrm), rtol=1e-4, atol=1e-5)
 
 
+def test_fused_edge_chain_full_size(device):
+    """BASELINE's full size (one packed cloud of 80 000 points, K = 16, 1.28 M edges): the fused three-pass backward
+    (weight gradients of the first layers from moments accumulated over all edges) against the layer-at-a-time
+    kernels behind the same fused forward.  Parameter gradients within 1e-3 of the largest entry; analytically
+    zero ones (biases in front of a batch-stat BN, the guidance shift) are rounding noise on both sides."""
+    import pcf_cuda
+    import pcf_layers
+    g = torch.Generator().manual_seed(1)
+    N, K = 80000, 16
+    xyz = torch.rand(1, N, 3, generator=g).to(device)
+    nrm = torch.nn.functional.normalize(torch.randn(1, N, 3, generator=g), dim=-1).to(device)
+    feats = torch.randn(1, N, 64, generator=g).to(device)
+    off = torch.tensor([0, N], dtype=torch.int32, device=device)
+    idx = pcf_cuda.knn_packed(xyz[0], xyz[0], off, off, K)[None].contiguous()
+    up = torch.randn(1, N, 64, generator=g).to(device)
+    res = {}
+    for mode in ('fused', 'layerwise_bwd'):
+        torch.manual_seed(7)
+        layer = pcf_layers.PCFLayer(64, 64, cfg(**CHAIN_MODES[mode]), weightnet=[12, 16], num_heads=8,
+                                    guidance_feat_len=32).to(device).train()
+        with torch.no_grad():
+            for m in layer.modules():
+                if isinstance(m, torch.nn.BatchNorm1d):
+                    m.weight.uniform_(0.5, 1.5)
+                    m.bias.uniform_(-0.3, 0.3)
+        x = feats.clone().requires_grad_(True)
+        out, _ = layer(xyz, x, idx, nrm)
+        out.backward(up)
+        res[mode] = dict(out=out.detach(), x=x.grad, **{n: p.grad for n, p in layer.named_parameters()})
+    torch.testing.assert_close(res['fused']['out'], res['layerwise_bwd']['out'], rtol=0, atol=0)     # same forward kernels
+    top = max(float(t.abs().max()) for k, t in res['layerwise_bwd'].items() if k not in ('out', 'x'))
+    for k, v in res['fused'].items():
+        ref = res['layerwise_bwd'][k]
+        scale = float(ref.abs().max()) + 1e-12
+        torch.testing.assert_close(v, ref, rtol=1e-3, atol=1e-3 * scale + 1e-5 * top, msg=lambda m, n=k: f'{n}: {m}')
+
+
 def test_fused_edge_chain_inference(device):
     """eval(): the chain runs its single inference pass on the running statistics.  Against the layer-at-a-time
     kernels, after one training step so the running statistics moved (they are compared too).  (PCFLayer needs the
