@@ -4,13 +4,13 @@
 // training mode couples every edge: with g = dy * act'(.), xhat the normalised pre-activation,
 //     dz = gamma * rstd * (g - mean(g) - xhat * mean(g * xhat)),    dbeta = sum g,   dgamma = sum g * xhat
 // so layer l's dz needs two global sums that depend on the dz of the layer above it -- three dependent
-// reductions down each branch.  Layer-at-a-time execution (edge_mlp_mfma.hip) reads and writes every
-// [E, 8..32] activation and gradient twice per layer (~2 kB per edge).  Here each of four passes recomputes what
+// reductions down each branch (the last one is removed by linearity, below).  Layer-at-a-time execution (edge_mlp_mfma.hip) reads and writes every
+// [E, 8..32] activation and gradient twice per layer (~2 kB per edge).  Here each of three passes recomputes what
 // it needs and walks the gradient down to the first layer whose sums are still unknown.  The forward keeps ONE
 // thing per branch: the raw 8-channel accumulator of the middle layer (g1 / w2: 2 x 32 B per edge, written by
-// pass 3 of edge_chain.hip).  From it the top layer (g2 / w3) is one 8-wide product away, so passes 1 and 2 never
+// pass 2 of edge_chain.hip).  From it the top layer (g2 / w3) is one 8-wide product away, so passes 1 and 2 never
 // touch VI, the gathered term or the key subtraction; the first layers (mlp_conv / w1) are recomputed from the
-// 48-byte VI row only where their masks and inputs are needed (passes 3 and 4):
+// 48-byte VI row only where their masks and inputs are needed (pass 3):
 //     pass 1: sums of g2 and w3                                  (reads the two accumulators, dscore, dw)
 //     pass 2: dz of g2, w3 -> dW of g2, w3;  g = dh1, da2 masked by the ReLU of g1, w2 -> stored (2 x 32 B per
 //             edge) with their sums: the top layers are finished here and never touched again
@@ -40,7 +40,7 @@ namespace pcf {
 constexpr int TT = 20;              // row stride of the 16x16 transposition tiles ([edge][channel], 16-byte aligned rows)
 constexpr int NFRAG = 13;
 constexpr int NSLOT = 7;            // output-tile slots: pe lo, pe hi, w1, g1, w2, g2, w3
-constexpr int NDW = 8;              // 16x16 weight-gradient tiles: pe lo, pe hi, w1, g1 (in lo), g1 (in hi), w2, g2, w3
+constexpr int NDW = 8;              // 16x16 tiles a workgroup of pass 3 accumulates (see chain_bwd_reduce_kernel)
 // per-channel constants of a slot: pre-activation = acc * SC + SH (acc = raw accumulator, bias folded in),
 // dz = g * SC + acc * D1 + D0  (the BatchNorm backward written in terms of the raw accumulator, see stage_consts)
 enum { K_SC = 0, K_SH = 1, K_D0 = 2, K_D1 = 3, NCONST = 4 };
@@ -54,7 +54,7 @@ struct ChainBwdArgs {
     const float* a2_acc;        // [E, 8] raw accumulator of w2
     const float* gmean[6];      // mean over edges of g          (device [64] per layer, filled pass by pass)
     const float* gxmean[6];     // mean over edges of g * xhat
-    float* gh1;                 // [E, 8] dh1 * [h1 > 0], written by pass 2, read by passes 3-4 (workspace)
+    float* gh1;                 // [E, 8] dh1 * [h1 > 0], written by pass 2, read by pass 3 (workspace)
     float* ga2;                 // [E, 8] da2 * [a2 > 0]
     float* part_top;            // [blocks][2][256] dW tiles of g2 / w3 from pass 2
     float* du;                  // [B*N, 8], zeroed by the host; float atomics
@@ -199,7 +199,7 @@ struct TileIO {
 // each wave then holds the live state of one branch only -- about half the registers, twice the resident waves.
 //
 // Guidance branch: VI -> pe (<= 32) -> g1 (8, + gathered u, - key) -> g2 (heads, sigmoid).
-//   red (LEVEL < 4): groups {L1: g2 | L2: g1 | L3: pe lo, pe hi};   LEVEL 4: dW tiles 0, 1, 3, 4, 6 and du.
+//   sums: groups {L1: g2 | L2: g1 | L3: pe lo, pe hi};   L2: dW tile of g2;   L3: tiles 0, 1, 3, 4, 6 and du.
 template <int LEVEL>
 __device__ __forceinline__ void guidance_branch(const ChainBwdArgs& a, const float (*cf)[NCONST][16], const float4* wl,
                                                 float* red, float* red_s, float* red_top, float* tb, int* gi,
@@ -214,7 +214,7 @@ __device__ __forceinline__ void guidance_branch(const ChainBwdArgs& a, const flo
     const bool first = (p & (f.K - 1)) == 0;
     BatchWalk walk;
     walk.init(f.rows_per_batch);
-    auto load_j = [&](long long tt) -> long long {               // called with increasing tt only; LEVEL 4 (du rows)
+    auto load_j = [&](long long tt) -> long long {               // called with increasing tt only; pass 3 (du rows)
         const int batch = walk.batch_of(tt * 16, p);
         const int64_t j = f.idx[tt * 16 + p];
         return (j >= 0 && j < f.N) ? (long long)batch * f.N + j : -1;
@@ -247,7 +247,7 @@ __device__ __forceinline__ void guidance_branch(const ChainBwdArgs& a, const flo
             }
             continue;
         }
-        // ---- passes 3, 4: from the stored g of g1 down through the positional encoding ----
+        // ---- pass 3: from the stored g of g1 down through the positional encoding ----
         const f32x4 g_h1 = io.load_grad(a.gh1, t, CH);
         const f32x4 x = io.load_x(t);
         const long long j_cur = load_j(t);
@@ -331,7 +331,7 @@ __device__ __forceinline__ void guidance_branch(const ChainBwdArgs& a, const flo
 }
 
 // WeightNet branch: VI -> w1 (8) -> w2 (8) -> w3 (C_mid), ReLU each.
-//   red (LEVEL < 4): groups {L1: w3 -> 1 | L2: w2 -> 1 | L3: w1 -> 2};   LEVEL 4: dW tiles 2, 5, 7.
+//   sums: groups {L1: w3 -> 1 | L2: w2 -> 1 | L3: w1 -> 2};   L2: dW tile of w3;   L3: tiles 2, 5.
 template <int LEVEL>
 __device__ __forceinline__ void weightnet_branch(const ChainBwdArgs& a, const float (*cf)[NCONST][16], const float4* wl,
                                                  float* red, float* red_s, float* red_top, float* tb, long long t0,
@@ -365,7 +365,7 @@ __device__ __forceinline__ void weightnet_branch(const ChainBwdArgs& a, const fl
             }
             continue;
         }
-        // passes 3, 4: from the stored g of w2 down through w1
+        // pass 3: from the stored g of w2 down through w1
         const f32x4 g_a2 = io.load_grad(a.ga2, t, CH);
         const f32x4 x = io.load_x(t);
         const f32x4 ac_a1 = mm(wl, 2, lane, x, zero4);
@@ -429,9 +429,9 @@ template <int NG> __device__ __host__ inline int branch_rank(int b) {
 template <int NG> __host__ inline int branch_blocks(int grid, bool guidance) {       // grid is a multiple of 8
     return guidance ? (grid >> 3) * NG : (grid >> 3) * (8 - NG);
 }
-// matrix instructions per tile, guidance : WeightNet = 4 : 4 (pass 1), 12 : 12 (pass 2), 16 : 8 (pass 3), 32 : 16 (pass 4).
-// Measured: passes 1-3 do not care between 4 and 6 of 8 (they are closer to the memory side); pass 4 is 8 % faster
-// with 6 of 8 than with 5.
+// matrix instructions per tile, guidance : WeightNet = 4 : 4 (pass 1), 12 : 12 (pass 2), 36 : 16 (pass 3).
+// Measured: passes 1-2 do not care between 4 and 6 of 8 (they are closer to the memory side); pass 3 takes 147 us
+// with 6 of 8, 229 us with 5, 358 us with 7.
 template <int LEVEL> struct SplitOf { static constexpr int NG = LEVEL == 3 ? 6 : 5; };
 
 // at least 4 waves per SIMD (<= 128 VGPRs): the last pass lands on 132 without the bound and runs 196 us instead of 147
@@ -644,7 +644,7 @@ extern "C" {
 
 size_t pcf_hip_pcf_chain_backward_workspace_bytes(long long E) {
     // per-workgroup partials of passes 1-4, the 12 x 64 per-channel means, and the two [E, 8] gradients pass 2 hands
-    // to passes 3-4
+    // to pass 3
     return ((size_t)1024 * pcf::NDW * 256 + (size_t)1024 * 512 + (size_t)1024 * 96 + 4096 + 12 * 64) * 4 +
            (size_t)(E > 0 ? E : 0) * 2 * pcf::CH * 4 + 1024;
 }
