@@ -430,8 +430,8 @@ template <int NG> __host__ inline int branch_blocks(int grid, bool guidance) {  
     return guidance ? (grid >> 3) * NG : (grid >> 3) * (8 - NG);
 }
 // matrix instructions per tile, guidance : WeightNet = 4 : 4 (pass 1), 12 : 12 (pass 2), 36 : 16 (pass 3).
-// Measured: passes 1-2 do not care between 4 and 6 of 8 (they are closer to the memory side); pass 3 takes 147 us
-// with 6 of 8, 229 us with 5, 358 us with 7.
+// Measured: passes 1-2 do not care between 4 and 6 of 8 (they are closer to the memory side); pass 3 took 196 us
+// with 6 of 8, 229 us with 5, 358 us with 7 (before the 128-VGPR bound, which brings 6 of 8 to 147 us).
 template <int LEVEL> struct SplitOf { static constexpr int NG = LEVEL == 3 ? 6 : 5; };
 
 // at least 4 waves per SIMD (<= 128 VGPRs): the last pass lands on 132 without the bound and runs 196 us instead of 147
