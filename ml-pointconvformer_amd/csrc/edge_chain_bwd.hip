@@ -645,7 +645,7 @@ extern "C" {
 size_t pcf_hip_pcf_chain_backward_workspace_bytes(long long E) {
     // per-workgroup partials of passes 1-4, the 12 x 64 per-channel means, and the two [E, 8] gradients pass 2 hands
     // to pass 3
-    return ((size_t)1024 * pcf::NDW * 256 + (size_t)1024 * 512 + (size_t)1024 * 96 + 4096 + 12 * 64) * 4 +
+    return ((size_t)1024 * pcf::NDW * 256 + (size_t)1024 * 512 + (size_t)2048 * 96 + 4096 + 12 * 64) * 4 +
            (size_t)(E > 0 ? E : 0) * 2 * pcf::CH * 4 + 1024;
 }
 
@@ -693,7 +693,7 @@ int pcf_hip_pcf_chain_backward(const float* vi, const int64_t* idx, const float*
     a.part = means + 12 * 64;
     a.part_top = a.part + (size_t)1024 * NDW * 256;
     a.part_sums = a.part_top + (size_t)1024 * 512;
-    float* redbuf = a.part_sums + (size_t)1024 * 96;   // RED_TOTAL <= 4096 floats
+    float* redbuf = a.part_sums + (size_t)2048 * 96;   // RED_TOTAL <= 4096 floats
     a.gh1 = redbuf + 4096;                             // 16-byte aligned: every region is a multiple of 64 floats
     a.ga2 = a.gh1 + (size_t)E * CH;
     for (int l = 0; l < 6; ++l) {
@@ -704,12 +704,15 @@ int pcf_hip_pcf_chain_backward(const float* vi, const int64_t* idx, const float*
     a.dscore = dscore; a.dw = dw; a.du = du; a.h1_acc = h1_acc; a.a2_acc = a2_acc;
     // both branches need at least one workgroup; a multiple of 8 keeps the 5 : 3 split exact
     const int grid = std::max(8, (chain_grid(E) + 7) / 8 * 8);
+    // pass 1 mostly streams (2048 workgroups keep more bytes in flight: 57 -> 49 us); passes 2-3 stay at 1024
+    const long long wg_needed = (E / 16 + NWAVE - 1) / NWAVE;
+    const int grid1 = std::max(8, (int)((std::min<long long>(wg_needed, 2048) + 7) / 8 * 8));
     for (int pass = 0; pass < 2; ++pass) {
-        if (pass == 0) hipLaunchKernelGGL(pcf_chain_bwd_kernel<1>, dim3(grid), dim3(BLOCK), 0, s, a, grid / 8);
+        if (pass == 0) hipLaunchKernelGGL(pcf_chain_bwd_kernel<1>, dim3(grid1), dim3(BLOCK), 0, s, a, grid1 / 8);
         else hipLaunchKernelGGL(pcf_chain_bwd_kernel<2>, dim3(grid), dim3(BLOCK), 0, s, a, grid / 8);
         if (int e = check_launch("pcf_chain_backward pass")) return e;
         BwdFinArgs fa{};
-        fa.part = a.part_sums; fa.nblocks = grid; fa.R = E;
+        fa.part = a.part_sums; fa.nblocks = pass == 0 ? grid1 : grid; fa.R = E;
         auto set = [&](int q, int layer, int chan0, int count) {
             fa.g[q].dbeta = dbeta[layer]; fa.g[q].dgamma = dgamma[layer];
             fa.g[q].gmean = means + layer * 64; fa.g[q].gxmean = means + (6 + layer) * 64;
