@@ -291,6 +291,23 @@ int pcf_hip_pcf_chain_backward(const float* vi, const int64_t* idx, const float*
                                float* const* db, float* const* dgamma, float* const* dbeta, void* workspace,
                                size_t workspace_bytes, void* stream);
 
+/* WeightNet alone (layers.py:127-191: Linear_BN + ReLU x 3, cin -> 8 -> 8 -> C_mid), the branch every PointConv-family
+ * layer feeds its aggregate with: same kernels as the WeightNet branch of the fused PCFLayer edge graph, no
+ * neighbourhood structure needed (strided / transposed / any K).  x [E, cin] (cin <= 12), E % 16 == 0, C_mid <= 16.
+ * Arrays of 3: w1, w2, w3.  stats [12][64] as above (rows 3..5 and 9..11 are used).  a2_acc [E, 8] (training):
+ * raw accumulator of w2, restart point of the last two forward passes and of the backward. */
+int pcf_hip_weightnet_chain_forward(const float* x, long long E, int cin, int cm, const float* const* W,
+                                    const float* const* b, const float* const* gamma, const float* const* beta,
+                                    float* const* running_mean, float* const* running_var, float eps, float momentum,
+                                    int batch_stats, float* stats, float* a2_acc, float* w, void* workspace,
+                                    size_t workspace_bytes, void* stream);
+/* workspace: pcf_hip_pcf_chain_backward_workspace_bytes(E) */
+int pcf_hip_weightnet_chain_backward(const float* x, const float* a2_acc, const float* dw, long long E, int cin, int cm,
+                                     const float* const* W, const float* const* b, const float* const* gamma,
+                                     const float* const* beta, const float* stats, float* const* dW, float* const* db,
+                                     float* const* dgamma, float* const* dbeta, void* workspace, size_t workspace_bytes,
+                                     void* stream);
+
 /* ---- dense fp32 contraction used by the linear stage (exposed for tests / roofline) ----------
  * C[M,N] = A[M,Kd] . B^T  (+ bias[N] if bias != NULL), B given as [N,Kd] row-major.  MFMA f32. */
 int pcf_hip_gemm_nt(const float* A, const float* Bm, const float* bias, float* C, int M, int N, int Kd,

@@ -42,7 +42,7 @@ __device__ __forceinline__ void stage_frags(const ChainArgs& a, float (*cf)[2][1
         const int f = t >> 4, c = t & 15;
         const int layer = layer_of[f], o = 16 * tile_of[f] + c;
         float sc = 1.f, sh = 0.f;
-        if (o < cout_of[f] && level >= need_level[f]) {
+        if (o < cout_of[f] && level >= need_level[f] && a.gamma[layer]) {        // null: layer absent (WeightNet-only use)
             sc = a.rstd[layer][o] * a.gamma[layer][o];
             sh = (a.b[layer][o] - a.mean[layer][o]) * sc + a.beta[layer][o];
         }
@@ -335,6 +335,93 @@ __global__ __launch_bounds__(BLOCK) void pcf_chain_tail_kernel(const ChainArgs a
     }
 }
 
+// ---- WeightNet alone (PointConv family: layers.py:127-191 feeding pconv / pconv_linear) -------------------------
+// The same three-layer branch (cin -> 8 -> 8 -> C_mid, Linear + BatchNorm + ReLU each) without a guidance branch:
+// any neighbourhood structure (strided, transposed, any K), one lane group per edge row.
+//   LEVEL 1: statistics of w1                (reads the input row)
+//   LEVEL 2: statistics of w2, stores its raw accumulator a2_acc [E, 8]
+//   LEVEL 3: statistics of w3 from a2_acc    LEVEL 4: w = relu(BN(w3)) from a2_acc (FROM_ACC) or from the input row
+//            (inference: running statistics, one pass)
+template <int LEVEL, bool FROM_ACC>
+__global__ __launch_bounds__(BLOCK) void wn_chain_kernel(const ChainArgs a) {
+    __shared__ float red[NWAVE][3][2][16];
+    __shared__ __align__(16) float cf[7][2][16];
+    stage_frags(a, cf, LEVEL);
+    for (int t = threadIdx.x; t < NWAVE * 96; t += BLOCK) (&red[0][0][0][0])[t] = 0.f;
+    __syncthreads();
+    const int lane = lane_id(), wave = wave_id();
+    const int p = lane & 15, g = lane >> 4;
+    f32x4 w_w1, w_w2, w_w3;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        w_w1[s] = FROM_ACC ? 0.f : wfrag(a.W[L_W1], CH, a.cv, p, 4 * g + s);
+        w_w2[s] = (FROM_ACC || LEVEL < 2) ? 0.f : wfrag(a.W[L_W2], CH, CH, p, 4 * g + s);
+        w_w3[s] = LEVEL >= 3 ? wfrag(a.W[L_W3], a.cm, CH, p, 4 * g + s) : 0.f;
+    }
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 s1 = zero4, s2 = zero4;
+    const long long ntiles = a.E / 16;
+    for (long long t = (long long)blockIdx.x * NWAVE + wave; t < ntiles; t += (long long)gridDim.x * NWAVE) {
+        const long long e = t * 16 + p;
+        f32x4 a2 = zero4;
+        if (FROM_ACC) {
+            if (g < 2) { const float4 v = ld4(a.a2_acc + (size_t)e * CH + 4 * g); a2 = f32x4{v.x, v.y, v.z, v.w}; }
+        } else {
+            f32x4 x = zero4;
+            if (4 * g < a.cv) {
+                const float* q = a.vi + (size_t)e * a.cv + 4 * g;
+                if (a.vec_vi) { const float4 v = ld4(q); x = f32x4{v.x, v.y, v.z, v.w}; }
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x[r] = (4 * g + r < a.cv) ? q[r] : 0.f;
+                }
+            }
+            f32x4 a1 = zero4;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) a1 = PCF_MFMA(w_w1[s], x[s], a1);
+            if (LEVEL == 1) { s1 += a1; s2 += a1 * a1; continue; }
+            a1 = bn_relu(a1, cf[2], g);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) a2 = PCF_MFMA(w_w2[s], a1[s], a2);
+            if (LEVEL == 2) {
+                if (a.a2_acc && g < 2) st4(a.a2_acc + (size_t)e * CH + 4 * g, make_float4(a2[0], a2[1], a2[2], a2[3]));
+                s1 += a2; s2 += a2 * a2;
+                continue;
+            }
+        }
+        a2 = bn_relu(a2, cf[4], g);
+        if (g >= 2) a2 = zero4;                          // channels 8..15 do not exist
+        f32x4 wv = zero4;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) wv = PCF_MFMA(w_w3[s], a2[s], wv);
+        if (LEVEL == 3) { s1 += wv; s2 += wv * wv; continue; }
+        wv = bn_relu(wv, cf[6], g);
+        float* qw = a.w + (size_t)e * a.cm;
+        if ((a.cm & 3) == 0) { if (4 * g < a.cm) st4(qw + 4 * g, make_float4(wv[0], wv[1], wv[2], wv[3])); }
+        else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (4 * g + r < a.cm) qw[4 * g + r] = wv[r];
+        }
+    }
+    if (LEVEL == 4) return;
+    const int gi = LEVEL == 1 ? 2 : 1;                      // group of the partial list: w1 -> 2, w2 / w3 -> 1
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float v1 = s1[r], v2 = s2[r];
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) { v1 += __shfl_xor(v1, off, WAVE); v2 += __shfl_xor(v2, off, WAVE); }
+        if (p == 0) { red[wave][gi][0][4 * g + r] = v1; red[wave][gi][1][4 * g + r] = v2; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 96) {
+        const int q = threadIdx.x / 32, which = (threadIdx.x >> 4) & 1, c = threadIdx.x & 15;
+        float tsum = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWAVE; ++w) tsum += red[w][q][which][c];
+        a.part[(size_t)blockIdx.x * 96 + threadIdx.x] = tsum;
+    }
+}
+
 // Statistics of one pass: up to three groups of 16 channels; each group belongs to a layer at a channel
 // offset.  One thread per (group, channel): fp64 sum over the workgroup partials.
 struct FinGroup { float* mean; float* rstd; float* running_mean; float* running_var; const float* bias; int chan0; int count; };
@@ -456,6 +543,63 @@ int pcf_hip_pcf_chain_forward(const float* vi, const int64_t* idx, const float* 
         hipLaunchKernelGGL(pcf_chain_kernel<4>, dim3(chain_grid(E)), dim3(BLOCK), 0, s, a);
     }
     return check_launch("pcf_chain final pass");
+}
+
+// WeightNet alone.  Layer order w1, w2, w3; stats [12][64] laid out as for the full chain (mean of layer l at
+// stats + 64*l with l = 3, 4, 5 for w1, w2, w3; rstd at stats + 64*(6+l)).  cin <= 12, hidden widths 8, cm <= 16,
+// E % 16 == 0.  a2_acc (nullable in inference) receives the raw accumulator of w2 for the fused backward.
+int pcf_hip_weightnet_chain_forward(const float* x, long long E, int cin, int cm, const float* const* W,
+                                    const float* const* b, const float* const* gamma, const float* const* beta,
+                                    float* const* running_mean, float* const* running_var, float eps, float momentum,
+                                    int batch_stats, float* stats, float* a2_acc, float* w, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+    using namespace pcf;
+    PCF_REQUIRE(E >= 0, "weightnet_chain: bad sizes");
+    if (cin < 1 || cin > CV || cm < 1 || cm > CMX || E % 16 != 0)
+        return fail(PCF_E_UNSUPPORTED, "weightnet_chain: needs cin <= 12, C_mid <= 16 and a multiple of 16 edges (cin=%d cm=%d)", cin, cm);
+    if (E == 0) return ok();
+    PCF_REQUIRE(x && W && b && gamma && beta && stats && w, "weightnet_chain: null pointer");
+    PCF_REQUIRE(!batch_stats || a2_acc, "weightnet_chain: training needs the accumulator buffer");
+    PCF_REQUIRE(aligned16(w) && aligned16(a2_acc), "weightnet_chain: buffers must be 16-byte aligned");
+    PCF_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= pcf_hip_pcf_chain_workspace_bytes(),
+                "weightnet_chain: workspace too small or misaligned");
+    hipStream_t s = (hipStream_t)stream;
+    ChainArgs a{};
+    a.vi = x; a.E = E; a.rows_per_batch = E; a.cv = cin; a.g = 0; a.heads = 0; a.cm = cm; a.K = 1;
+    const int layers[3] = {L_W1, L_W2, L_W3};
+    for (int i = 0; i < 3; ++i) {
+        const int l = layers[i];
+        PCF_REQUIRE(W[i] && b[i] && gamma[i] && beta[i], "weightnet_chain: null parameter of layer %d", i);
+        a.W[l] = W[i]; a.b[l] = b[i]; a.gamma[l] = gamma[i]; a.beta[l] = beta[i];
+    }
+    for (int l = 0; l < 6; ++l) { a.mean[l] = stats + l * 64; a.rstd[l] = stats + (6 + l) * 64; }
+    a.a2_acc = a2_acc; a.w = w;
+    a.part = static_cast<float*>(workspace);
+    a.vec_vi = (cin % 4 == 0) && aligned16(x);
+    const int grid = chain_grid(E);
+    if (!batch_stats) {
+        hipLaunchKernelGGL((wn_chain_kernel<4, false>), dim3(grid), dim3(BLOCK), 0, s, a);
+        return check_launch("weightnet_chain inference pass");
+    }
+    for (int pass = 0; pass < 3; ++pass) {
+        if (pass == 0) hipLaunchKernelGGL((wn_chain_kernel<1, false>), dim3(grid), dim3(BLOCK), 0, s, a);
+        else if (pass == 1) hipLaunchKernelGGL((wn_chain_kernel<2, false>), dim3(grid), dim3(BLOCK), 0, s, a);
+        else hipLaunchKernelGGL((wn_chain_kernel<3, true>), dim3(grid), dim3(BLOCK), 0, s, a);
+        if (int e = check_launch("weightnet_chain pass")) return e;
+        FinArgs f{};
+        f.part = a.part; f.nblocks = grid; f.R = E; f.eps = eps; f.momentum = momentum;
+        const int i = pass, l = layers[pass];
+        const int gi = pass == 0 ? 2 : 1;
+        f.g[gi].mean = stats + l * 64; f.g[gi].rstd = stats + (6 + l) * 64;
+        f.g[gi].running_mean = running_mean ? running_mean[i] : nullptr;
+        f.g[gi].running_var = running_var ? running_var[i] : nullptr;
+        f.g[gi].bias = b[i]; f.g[gi].chan0 = 0; f.g[gi].count = pass == 2 ? cm : CH;
+        hipLaunchKernelGGL(chain_finalize_kernel, dim3(12), dim3(1024), 0, s, f);
+        if (int e = check_launch("weightnet_chain finalize")) return e;
+    }
+    hipLaunchKernelGGL((wn_chain_kernel<4, true>), dim3(std::min<long long>(2048, std::max<long long>(1, (E / 16 + NWAVE - 1) / NWAVE))),
+                       dim3(BLOCK), 0, s, a);
+    return check_launch("weightnet_chain final pass");
 }
 
 }  // extern "C"

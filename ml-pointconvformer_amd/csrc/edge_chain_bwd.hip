@@ -58,6 +58,7 @@ struct ChainBwdArgs {
     float* ga2;                 // [E, 8] da2 * [a2 > 0]
     float* part_top;            // [blocks][2][256] dW tiles of g2 / w3 from pass 2
     float* du;                  // [B*N, 8], zeroed by the host; float atomics
+    int wn_only;                // WeightNet alone: every workgroup runs that branch (and accumulates the VI' moments)
     float* part;                // [blocks][NDW][256] dW / moment tiles of pass 3
     float* part_sums;           // [blocks][96] per-channel sums of the running pass
 };
@@ -76,7 +77,7 @@ __device__ __forceinline__ void stage_consts(const ChainBwdArgs& a, float (*cf)[
         const int s = t >> 4, c = t & 15;
         const int layer = layer_of[s], o = 16 * tile_of[s] + c;
         float v[NCONST] = {0.f, 0.f, 0.f, 0.f};
-        if (o < cout_of[s]) {
+        if (o < cout_of[s] && a.f.gamma[layer]) {          // null: layer absent (WeightNet-only use)
             const float rs = a.f.rstd[layer][o], x0 = (a.f.b[layer][o] - a.f.mean[layer][o]) * rs;
             v[K_SC] = rs * a.f.gamma[layer][o];
             v[K_SH] = x0 * a.f.gamma[layer][o] + a.f.beta[layer][o];
@@ -384,16 +385,18 @@ __device__ __forceinline__ void weightnet_branch(const ChainBwdArgs& a, const fl
             put_tile(tb + 0 * 16 * TT, g_a1, p, g);
             put_tile(tb + 1 * 16 * TT, x1, p, g);
             accw[0] = outer(tb + 0 * 16 * TT, tb + 1 * 16 * TT, p, g, accw[0]);
+            if (a.wn_only) accw[2] = outer(tb + 1 * 16 * TT, tb + 1 * 16 * TT, p, g, accw[2]);     // no guidance workgroups
         }
     }
     if (LEVEL == 3) {
-        const int tiles[2] = {2, 5};            // 2: sum g_a1 (x) VI' | 5: dW of w2
+        const int tiles[3] = {2, 5, 6};         // 2: sum g_a1 (x) VI' | 5: dW of w2 | 6: sum VI' (x) VI' (wn_only)
         for (int wv = 0; wv < NWAVE; ++wv) {
             if (wave == wv) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 3; ++i)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) red[tiles[i] * 256 + (4 * g + r) * 16 + p] += accw[i][r];
+                    for (int r = 0; r < 4; ++r)
+                        if (i < 2 || a.wn_only) red[tiles[i] * 256 + (4 * g + r) * 16 + p] += accw[i][r];
             }
             __syncthreads();
         }
@@ -456,7 +459,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) v
     float* tb = LEVEL == 3 ? tbuf + wave * 3 * 16 * TT : (LEVEL == 2 ? tbuf + wave * 2 * 16 * TT : tbuf);
     constexpr int NG = SplitOf<LEVEL>::NG;
     const int rank = branch_rank<NG>(blockIdx.x);
-    if (is_guidance_block<NG>(blockIdx.x))
+    if (a.wn_only)
+        weightnet_branch<LEVEL>(a, cf, wl, red, red_s, red_top, tb, (long long)blockIdx.x * NWAVE + wave,
+                                (long long)gridDim.x * NWAVE);
+    else if (is_guidance_block<NG>(blockIdx.x))
         guidance_branch<LEVEL>(a, cf, wl, red, red_s, red_top, tb, gi[wave], (long long)rank * NWAVE + wave,
                                (long long)grid8 * NG * NWAVE);
     else
@@ -606,7 +612,7 @@ __global__ __launch_bounds__(BLOCK) void chain_bwd_combine_kernel(const BwdCombi
     if (tid >= 64 && tid < 64 + 6 * 32) {
         const int l = (tid - 64) >> 5, o = (tid - 64) & 31;
         const int couts[6] = {f.g, CH, f.heads, CH, CH, f.cm};
-        if (o < couts[l]) f.db[l][o] = 0.f;
+        if (o < couts[l] && f.db[l]) f.db[l][o] = 0.f;
     }
     __syncthreads();
     const float* XX = red + 6 * 256;                 // [c'][c] = sum VI'[c'] VI'[c], VI'[12] = 1
@@ -640,16 +646,7 @@ __global__ __launch_bounds__(BLOCK) void chain_bwd_combine_kernel(const BwdCombi
 
 }  // namespace pcf
 
-extern "C" {
-
-size_t pcf_hip_pcf_chain_backward_workspace_bytes(long long E) {
-    // per-workgroup partials of passes 1-4, the 12 x 64 per-channel means, and the two [E, 8] gradients pass 2 hands
-    // to pass 3
-    return ((size_t)1024 * pcf::NDW * 256 + (size_t)1024 * 512 + (size_t)2048 * 96 + 4096 + 12 * 64) * 4 +
-           (size_t)(E > 0 ? E : 0) * 2 * pcf::CH * 4 + 1024;
-}
-
-int pcf_hip_pcf_chain_backward(const float* vi, const int64_t* idx, const float* h1_acc, const float* a2_acc,
+static int chain_backward_impl(bool wn_only, const float* vi, const int64_t* idx, const float* h1_acc, const float* a2_acc,
                                const float* dscore, const float* dw, long long E, long long rows_per_batch, int N, int K, int cv, int g, int heads, int cm,
                                const float* const* W, const float* const* b, const float* const* gamma,
                                const float* const* beta, const float* stats, float* du, float* const* dW, float* const* db,
@@ -657,15 +654,16 @@ int pcf_hip_pcf_chain_backward(const float* vi, const int64_t* idx, const float*
                                void* stream) {
     using namespace pcf;
     PCF_REQUIRE(E >= 0 && rows_per_batch > 0 && N >= 0, "pcf_chain_backward: bad sizes");
-    if (cv < 1 || cv > CV || g < 1 || g > CG || heads < 1 || heads > CHD || cm < 1 || cm > CMX)
+    if (cv < 1 || cv > CV || cm < 1 || cm > CMX || (!wn_only && (g < 1 || g > CG || heads < 1 || heads > CHD)))
         return fail(PCF_E_UNSUPPORTED, "pcf_chain_backward: widths outside the fused kernel (cv=%d<=12, g=%d<=32, heads=%d<=8, cm=%d<=16)", cv, g, heads, cm);
-    if (K < 1 || K > 16 || (K & (K - 1)) != 0 || E % 16 != 0 || E % rows_per_batch != 0 || rows_per_batch < 16)
+    if (E % 16 != 0 || (!wn_only && (K < 1 || K > 16 || (K & (K - 1)) != 0 || E % rows_per_batch != 0 || rows_per_batch < 16)))
         return fail(PCF_E_UNSUPPORTED, "pcf_chain_backward: K must be a power of two <= 16, the edge count a multiple of 16 and >= 16 edges per batch (K=%d)", K);
-    PCF_REQUIRE(W && b && gamma && beta && stats && du && dW && db && dgamma && dbeta, "pcf_chain_backward: null pointer");
+    PCF_REQUIRE(W && b && gamma && beta && stats && (du || wn_only) && dW && db && dgamma && dbeta, "pcf_chain_backward: null pointer");
     hipStream_t s = (hipStream_t)stream;
     const int couts[6] = {g, CH, heads, CH, CH, cm};
     const int cins[6] = {cv, g, CH, cv, CH, CH};
     for (int l = 0; l < 6; ++l) {
+        if (wn_only && l < 3) continue;                   // no guidance layers
         PCF_REQUIRE(W[l] && b[l] && gamma[l] && beta[l] && dW[l] && db[l] && dgamma[l] && dbeta[l],
                     "pcf_chain_backward: null parameter of layer %d", l);
         if (E == 0) {
@@ -676,10 +674,10 @@ int pcf_hip_pcf_chain_backward(const float* vi, const int64_t* idx, const float*
         }
     }
     const long long batches = E / rows_per_batch;
-    if (batches * N > 0 && hipMemsetAsync(du, 0, (size_t)batches * N * CH * 4, s) != hipSuccess)
+    if (!wn_only && batches * N > 0 && hipMemsetAsync(du, 0, (size_t)batches * N * CH * 4, s) != hipSuccess)
         return fail(PCF_E_LAUNCH, "pcf_chain_backward: memset");
     if (E == 0) return ok();
-    PCF_REQUIRE(vi && idx && h1_acc && a2_acc && dscore && dw, "pcf_chain_backward: null pointer");
+    PCF_REQUIRE(vi && a2_acc && dw && (wn_only || (idx && h1_acc && dscore)), "pcf_chain_backward: null pointer");
     PCF_REQUIRE(aligned16(h1_acc) && aligned16(a2_acc) && aligned16(dscore) && aligned16(dw) && aligned16(du),
                 "pcf_chain_backward: buffers must be 16-byte aligned");
     PCF_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= pcf_hip_pcf_chain_backward_workspace_bytes(E),
@@ -701,7 +699,7 @@ int pcf_hip_pcf_chain_backward(const float* vi, const int64_t* idx, const float*
         a.f.mean[l] = stats + l * 64; a.f.rstd[l] = stats + (6 + l) * 64;
         a.gmean[l] = means + l * 64; a.gxmean[l] = means + (6 + l) * 64;
     }
-    a.dscore = dscore; a.dw = dw; a.du = du; a.h1_acc = h1_acc; a.a2_acc = a2_acc;
+    a.dscore = dscore; a.dw = dw; a.du = du; a.h1_acc = h1_acc; a.a2_acc = a2_acc; a.wn_only = wn_only ? 1 : 0;
     // both branches need at least one workgroup; a multiple of 8 keeps the 5 : 3 split exact
     const int grid = std::max(8, (chain_grid(E) + 7) / 8 * 8);
     // pass 1 mostly streams (2048 workgroups keep more bytes in flight: 57 -> 49 us); passes 2-3 stay at 1024
@@ -720,8 +718,8 @@ int pcf_hip_pcf_chain_backward(const float* vi, const int64_t* idx, const float*
             fa.g[q].chan0 = chan0; fa.g[q].count = count;
         };
         // (guidance workgroups fill group 0, WeightNet workgroups group 1; the rest are zeros)
-        if (pass == 0) { set(0, L_G2, 0, heads); set(1, L_W3, 0, cm); }
-        else { set(0, L_G1, 0, CH); set(1, L_W2, 0, CH); }
+        if (pass == 0) { if (!wn_only) set(0, L_G2, 0, heads); set(1, L_W3, 0, cm); }
+        else { if (!wn_only) set(0, L_G1, 0, CH); set(1, L_W2, 0, CH); }
         hipLaunchKernelGGL(chain_bwd_finalize_kernel, dim3(12), dim3(1024), 0, s, fa);
         if (int e = check_launch("pcf_chain_backward finalize")) return e;
     }
@@ -737,6 +735,46 @@ int pcf_hip_pcf_chain_backward(const float* vi, const int64_t* idx, const float*
     ca.R = E; ca.cv = cv; ca.g = g; ca.heads = heads; ca.cm = cm;
     hipLaunchKernelGGL(chain_bwd_combine_kernel, dim3(1), dim3(BLOCK), 0, s, ca);
     return check_launch("pcf_chain_backward parameter gradients");
+}
+
+
+extern "C" {
+
+size_t pcf_hip_pcf_chain_backward_workspace_bytes(long long E) {
+    // per-workgroup partials of passes 1-4, the 12 x 64 per-channel means, and the two [E, 8] gradients pass 2 hands
+    // to pass 3
+    return ((size_t)1024 * pcf::NDW * 256 + (size_t)1024 * 512 + (size_t)2048 * 96 + 4096 + 12 * 64) * 4 +
+           (size_t)(E > 0 ? E : 0) * 2 * pcf::CH * 4 + 1024;
+}
+
+int pcf_hip_pcf_chain_backward(const float* vi, const int64_t* idx, const float* h1_acc, const float* a2_acc,
+                               const float* dscore, const float* dw, long long E, long long rows_per_batch, int N, int K,
+                               int cv, int g, int heads, int cm, const float* const* W, const float* const* b,
+                               const float* const* gamma, const float* const* beta, const float* stats, float* du,
+                               float* const* dW, float* const* db, float* const* dgamma, float* const* dbeta,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+    return chain_backward_impl(false, vi, idx, h1_acc, a2_acc, dscore, dw, E, rows_per_batch, N, K, cv, g, heads, cm, W, b,
+                               gamma, beta, stats, du, dW, db, dgamma, dbeta, workspace, workspace_bytes, stream);
+}
+
+// WeightNet alone (adjoint of pcf_hip_weightnet_chain_forward): layer order w1, w2, w3 in every array.
+int pcf_hip_weightnet_chain_backward(const float* x, const float* a2_acc, const float* dw, long long E, int cin, int cm,
+                                     const float* const* W, const float* const* b, const float* const* gamma,
+                                     const float* const* beta, const float* stats, float* const* dW, float* const* db,
+                                     float* const* dgamma, float* const* dbeta, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+    using namespace pcf;
+    PCF_REQUIRE(W && b && gamma && beta && dW && db && dgamma && dbeta, "weightnet_chain_backward: null pointer");
+    const float* W6[6] = {nullptr, nullptr, nullptr, W[0], W[1], W[2]};
+    const float* b6[6] = {nullptr, nullptr, nullptr, b[0], b[1], b[2]};
+    const float* g6[6] = {nullptr, nullptr, nullptr, gamma[0], gamma[1], gamma[2]};
+    const float* be6[6] = {nullptr, nullptr, nullptr, beta[0], beta[1], beta[2]};
+    float* dW6[6] = {nullptr, nullptr, nullptr, dW[0], dW[1], dW[2]};
+    float* db6[6] = {nullptr, nullptr, nullptr, db[0], db[1], db[2]};
+    float* dg6[6] = {nullptr, nullptr, nullptr, dgamma[0], dgamma[1], dgamma[2]};
+    float* dbe6[6] = {nullptr, nullptr, nullptr, dbeta[0], dbeta[1], dbeta[2]};
+    return chain_backward_impl(true, x, nullptr, nullptr, a2_acc, nullptr, dw, E, E > 0 ? E : 1, 0, 1, cin, 0, 0, cm, W6, b6, g6,
+                               be6, stats, nullptr, dW6, db6, dg6, dbe6, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

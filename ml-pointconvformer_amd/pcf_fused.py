@@ -568,6 +568,83 @@ class _PCFChain(torch.autograd.Function):
         return (None, None, None, None, None, du, dfx, *grads)
 
 
+_wn_fwd = _sig('pcf_hip_weightnet_chain_forward',
+               [_P, _LL, _I, _I, _PP, _PP, _PP, _PP, _PP, _PP, _F, _F, _I, _P, _P, _P, _P, _Z, _P])
+_wn_bwd = _sig('pcf_hip_weightnet_chain_backward',
+               [_P, _P, _P, _LL, _I, _I, _PP, _PP, _PP, _PP, _P, _PP, _PP, _PP, _PP, _P, _Z, _P])
+
+
+class _WeightNetChain(torch.autograd.Function):
+    """w = WeightNet(x) through the fused three-layer chain (csrc/edge_chain*.hip, WeightNet branch only).
+    Tensor inputs: x [..., cin], then (W, b, gamma, beta) of w1, w2, w3."""
+
+    @staticmethod
+    def forward(ctx, bns, training, x, *params):
+        dev = x.device
+        cin = x.shape[-1]
+        E = x.numel() // cin
+        keep = [t.contiguous() for t in params]
+        Ws, bs, gammas, betas = keep[0::4], keep[1::4], keep[2::4], keep[3::4]
+        cm = Ws[2].shape[0]
+        f32 = dict(dtype=torch.float32, device=dev)
+        stats = torch.empty(12, 64, **f32)
+        if not training:
+            for i, bn in enumerate(bns):
+                c = bn.running_mean.numel()
+                stats[3 + i, :c] = bn.running_mean
+                stats[9 + i, :c] = torch.rsqrt(bn.running_var + bn.eps)
+        w = torch.empty(*x.shape[:-1], cm, **f32)
+        a2_acc = torch.empty(*x.shape[:-1], 8, **f32) if training else None
+        if training:
+            for bn in bns:
+                count_batch(bn)
+        nbytes = _chain_ws()
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        rm = _ptr_array([bn.running_mean for bn in bns]) if training else None
+        rv = _ptr_array([bn.running_var for bn in bns]) if training else None
+        mom = bns[0].momentum if bns[0].momentum is not None else 0.1
+        with torch.cuda.device(dev):
+            _call(_wn_fwd, _ptr(x), E, cin, cm, _ptr_array(Ws), _ptr_array(bs), _ptr_array(gammas), _ptr_array(betas), rm, rv,
+                  float(bns[0].eps), float(mom), 1 if training else 0, stats.data_ptr(), _ptr(a2_acc), _ptr(w),
+                  ws.data_ptr(), nbytes, _stream(dev))
+        ctx.save_for_backward(x, stats, a2_acc, *keep)
+        ctx.training = bool(training)
+        return w
+
+    @staticmethod
+    def backward(ctx, dw):
+        x, stats, a2_acc, *keep = ctx.saved_tensors
+        if not ctx.training:
+            raise RuntimeError('weightnet_chain: backward needs the training-mode forward (batch statistics)')
+        Ws, bs, gammas, betas = keep[0::4], keep[1::4], keep[2::4], keep[3::4]
+        dev = dw.device
+        cin = x.shape[-1]
+        E = x.numel() // cin
+        dw = dw.contiguous()
+        grads = [torch.empty_like(t) for t in keep]
+        nbytes = _chain_bwd_ws(E)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _call(_wn_bwd, _ptr(x), _ptr(a2_acc), _ptr(dw), E, cin, Ws[2].shape[0], _ptr_array(Ws), _ptr_array(bs),
+                  _ptr_array(gammas), _ptr_array(betas), stats.data_ptr(), _ptr_array(grads[0::4]), _ptr_array(grads[1::4]),
+                  _ptr_array(grads[2::4]), _ptr_array(grads[3::4]), ws.data_ptr(), nbytes, _stream(dev))
+        return (None, None, None, *grads)
+
+
+def weightnet_chain_supported(cin, hidden, cout, n_rows):
+    """Three Linear_BN layers cin -> 8 -> 8 -> cout with cin <= 12, cout <= 16, a multiple of 16 rows."""
+    return tuple(hidden) == (8, 8) and 1 <= cin <= 12 and 1 <= cout <= 16 and n_rows % 16 == 0 and n_rows > 0
+
+
+def weightnet_chain(x, layers, training):
+    """layers: three (nn.Linear, nn.BatchNorm1d) pairs.  The input carries no gradient (coordinates / VI)."""
+    _floats(x=x)
+    params = []
+    for lin, bn in layers:
+        params += [lin.weight, lin.bias, bn.weight, bn.bias]
+    return _WeightNetChain.apply([bn for _, bn in layers], training, x.contiguous(), *params)
+
+
 class _SplitColumns(torch.autograd.Function):
     """W [O, A+B] -> (W[:, :A], W[:, A:]) as contiguous tensors; the backward is one concatenation instead of two
     zero-fill + copy + accumulate chains of the slicing ops."""

@@ -278,7 +278,13 @@ class WeightNet(pcf_fused.CounterScope):
 
     def forward(self, localized_xyz):
         w = localized_xyz
-        for conv in self.mlp_convs:
+        convs = list(self.mlp_convs)
+        if len(convs) == 3 and not w.requires_grad and not getattr(self, 'no_chain', False) \
+                and pcf_fused.weightnet_chain_supported(convs[0].c.in_features, (convs[0].c.out_features, convs[1].c.out_features),
+                                                        convs[2].c.out_features, w.numel() // max(1, w.shape[-1])):
+            # the three layers in one fused chain (four passes forward, three backward; csrc/edge_chain*.hip)
+            return pcf_fused.weightnet_chain(w, [(m.c, m.bn) for m in convs], self.training)
+        for conv in convs:
             w = conv(w, pcf_fused.ACT_RELU)
         return w
 

@@ -528,6 +528,45 @@ def test_edge_geometry_store_paths(device, B, M, K):
         torch.testing.assert_close(vi.cpu(), O.vi_features(wrel, O.gather_rows(nrm, idx), cnrm), rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize('rows,cin,cout,training', [((2, 500, 16), 12, 16, True), ((1, 333, 16), 3, 16, True),
+                                                    ((3, 64, 8), 12, 1, True), ((1, 4096, 16), 12, 4, True),
+                                                    ((2, 100, 8), 3, 16, False)])
+def test_weightnet_chain_against_layer_at_a_time(device, rows, cin, cout, training):
+    """WeightNet (cin -> 8 -> 8 -> C_mid) through the fused chain (four passes forward, three backward) against the
+    same module run layer by layer: output, every parameter gradient, running statistics.  Includes the decoder's
+    C_mid = 1 and the 3-channel (no VI) input."""
+    import copy
+    import pcf_layers
+    torch.manual_seed(rows[1] + cin)
+    wn = pcf_layers.WeightNet(cin, cout, efficient=True).to(device)
+    with torch.no_grad():
+        for m in wn.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.3, 0.3)
+    ref = copy.deepcopy(wn)
+    ref.no_chain = True
+    wn.train(training)
+    ref.train(training)
+    x = torch.randn(*rows, cin, device=device)
+    import pcf_fused
+    assert pcf_fused.weightnet_chain_supported(cin, (8, 8), cout, x.numel() // cin)
+    out = wn(x)
+    want = ref(x)
+    torch.testing.assert_close(out, want, rtol=1e-4, atol=1e-5)
+    if not training:
+        return
+    up = torch.randn_like(out)
+    out.backward(up)
+    want.backward(up)
+    top = max(float(p.grad.abs().max()) for p in ref.parameters())
+    for (n, p), (_, q) in zip(wn.named_parameters(), ref.named_parameters()):
+        scale = float(q.grad.abs().max()) + 1e-12
+        torch.testing.assert_close(p.grad, q.grad, rtol=1e-3, atol=2e-4 * scale + 2e-5 * top, msg=lambda m, k=n: f'{k}: {m}')
+    for (n, b), (_, c) in zip(wn.named_buffers(), ref.named_buffers()):
+        torch.testing.assert_close(b.float(), c.float(), rtol=1e-4, atol=1e-5, msg=lambda m, k=n: f'{k}: {m}')
+
+
 def test_fused_edge_chain_full_size(device):
     """BASELINE's full size (one packed cloud of 80 000 points, K = 16, 1.28 M edges): the fused three-pass backward
     (weight gradients of the first layers from moments accumulated over all edges) against the layer-at-a-time
