@@ -32,7 +32,9 @@ __device__ __forceinline__ float bn_act_bwd(int act, float u) {
     return 1.f;
 }
 
-// Column partial sums of one or two per-element quantities.  Threads: TX column lanes x TY row lanes.
+// Column partial sums of one or two per-element quantities.  Threads: TX column lanes x TY row lanes; blockIdx.x
+// walks row ranges and blockIdx.y the TX-wide column chunks, so a short, wide matrix (1.4k x 512 at the coarse
+// levels) still spreads over the chip: one workgroup looping over its chunks is a serial chain of load latencies.
 //   MODE 0: (z, z*z)      MODE 1: (g, g*xhat) with g = dy * act'(u)
 template <int MODE>
 __global__ __launch_bounds__(BLOCK) void col_partials_kernel(const float* __restrict__ z, const float* __restrict__ dy,
@@ -46,8 +48,8 @@ __global__ __launch_bounds__(BLOCK) void col_partials_kernel(const float* __rest
     const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     const long long r1 = min(R, r0 + rows_per_block);
-    for (int c0 = 0; c0 < C; c0 += TX) {
-        const int c = c0 + tx;
+    {
+        const int c = blockIdx.y * TX + tx;
         float a = 0.f, b = 0.f;
         if (c < C) {
             float mu = 0.f, rs = 1.f, ga = 1.f, be = 0.f;
@@ -76,7 +78,6 @@ __global__ __launch_bounds__(BLOCK) void col_partials_kernel(const float* __rest
             part[((size_t)blockIdx.x * 2 + 0) * C + c] = a;
             part[((size_t)blockIdx.x * 2 + 1) * C + c] = b;
         }
-        __syncthreads();
     }
 }
 
@@ -205,8 +206,13 @@ __global__ __launch_bounds__(BLOCK) void bnact_bwd_kernel(const float* __restric
     }
 }
 
-static int stats_blocks(long long R) { return (int)std::max<long long>(1, std::min<long long>((R + 127) / 128, 1024)); }
 static int tx_for(int C) { int t = 1; while (t < C && t < 64) t <<= 1; return t; }
+// row ranges of the column reductions: >= 16 rows each, ~2048 workgroups over rows x column chunks, <= 1024 ranges
+static int stats_blocks(long long R, int C) {
+    const long long chunks = ceil_div(C, tx_for(C));
+    const long long want = std::max<long long>(256, 2048 / chunks);
+    return (int)std::max<long long>(1, std::min<long long>({(R + 15) / 16, want, 1024ll}));
+}
 // element-wise grids: every workgroup runs the same number of grid-stride rounds (a capped grid with a ragged
 // last round leaves most of the chip idle for up to half of a short kernel)
 static int ew_grid(long long n) {
@@ -221,7 +227,7 @@ extern "C" {
 
 size_t pcf_hip_bnact_workspace_bytes(long long R, int C) {
     if (R < 0 || C < 0) return 0;
-    return ((size_t)pcf::stats_blocks(R) * 2 * C + 2 * (size_t)C) * 4 + 256;
+    return ((size_t)pcf::stats_blocks(R, C) * 2 * C + 2 * (size_t)C) * 4 + 256;
 }
 
 int pcf_hip_bnact_stats(const float* z, long long R, int C, float eps, float momentum, float* running_mean,
@@ -234,9 +240,9 @@ int pcf_hip_bnact_stats(const float* z, long long R, int C, float eps, float mom
     PCF_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bnact_stats: need both running stats or none");
     hipStream_t s = (hipStream_t)stream;
     float* part = static_cast<float*>(workspace);
-    const int nb = stats_blocks(R);
+    const int nb = stats_blocks(R, C);
     const long long rpb = (R + nb - 1) / nb;
-    hipLaunchKernelGGL(col_partials_kernel<0>, dim3(nb), dim3(BLOCK), 0, s, z, nullptr, R, C, tx_for(C), rpb, nullptr, nullptr,
+    hipLaunchKernelGGL(col_partials_kernel<0>, dim3(nb, ceil_div(C, tx_for(C))), dim3(BLOCK), 0, s, z, nullptr, R, C, tx_for(C), rpb, nullptr, nullptr,
                        nullptr, nullptr, 0, part);
     hipLaunchKernelGGL(col_finalize_kernel<0>, dim3(ceil_div(C, FIN_COLS)), dim3(FIN_THREADS), 0, s, part, nb, R, C, eps, momentum,
                        running_mean, running_var, mean_out, rstd_out, nullptr, nullptr);
@@ -289,9 +295,9 @@ int pcf_hip_bnact_backward_res(const float* z, const float* residual, const floa
         float* wsf = static_cast<float*>(workspace);
         m1 = wsf; m2 = wsf + C;
         float* part = wsf + 2 * (size_t)C;
-        const int nb = stats_blocks(R);
+        const int nb = stats_blocks(R, C);
         const long long rpb = (R + nb - 1) / nb;
-        hipLaunchKernelGGL(col_partials_kernel<1>, dim3(nb), dim3(BLOCK), 0, s, z, dy, R, C, tx_for(C), rpb, mean, rstd, gamma,
+        hipLaunchKernelGGL(col_partials_kernel<1>, dim3(nb, ceil_div(C, tx_for(C))), dim3(BLOCK), 0, s, z, dy, R, C, tx_for(C), rpb, mean, rstd, gamma,
                            beta, act, part, residual);
         hipLaunchKernelGGL(col_finalize_kernel<1>, dim3(ceil_div(C, FIN_COLS)), dim3(FIN_THREADS), 0, s, part, nb, R, C, 0.f, 0.f, nullptr,
                            nullptr, dbeta, dgamma, m1, m2, batch_stats ? dbias_zero : nullptr);

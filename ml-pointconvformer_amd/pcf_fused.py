@@ -431,6 +431,65 @@ def wide_linear_bn_act(x, weight, bias, bn, act, training, residual=None):
                                   use_batch, act, residual)
 
 
+class _BNAct(torch.autograd.Function):
+    """act(BN(z)) over the last axis with the column-wise kernels of csrc/bnact.hip (no contraction in front)."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, running_mean, running_var, eps, momentum, training, act):
+        z = z.contiguous()
+        C = z.shape[-1]
+        R = z.numel() // C
+        dev = z.device
+        stream = _stream(dev)
+        y = torch.empty_like(z)
+        with torch.cuda.device(dev):
+            if training:
+                mean = torch.empty(C, dtype=torch.float32, device=dev)
+                rstd = torch.empty(C, dtype=torch.float32, device=dev)
+                nbytes = _bnact_ws(R, C)
+                ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                _call(_bnact_stats, _ptr(z), R, C, float(eps), float(momentum), _ptr(running_mean), _ptr(running_var),
+                      _ptr(mean), _ptr(rstd), ws.data_ptr(), nbytes, stream)
+            else:
+                mean, rstd = running_mean, torch.rsqrt(running_var + eps)
+            _call(_bnact_fwd, _ptr(z), None, R, C, _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), int(act), _ptr(y), stream)
+        ctx.save_for_backward(z, gamma, beta, mean, rstd)
+        ctx.cfg = (bool(training), int(act))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        z, gamma, beta, mean, rstd = ctx.saved_tensors
+        training, act = ctx.cfg
+        dy = dy.contiguous()
+        C = z.shape[-1]
+        R = z.numel() // C
+        dev = z.device
+        dz = torch.empty_like(z)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
+        nbytes = _bnact_ws(R, C)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _call(_bnact_bwd, _ptr(z), None, _ptr(dy), R, C, _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta),
+                  1 if training else 0, act, _ptr(dz), None, _ptr(dgamma), _ptr(dbeta), None, ws.data_ptr(), nbytes,
+                  _stream(dev))
+        return dz, dgamma, dbeta, None, None, None, None, None, None
+
+
+def bn_act(z, bn, act, training):
+    """act(bn(z)) for an nn.BatchNorm1d module over the last axis of z, in three HBM passes forward (statistics,
+    normalise + activate) and two backward.  Same statistics rules as nn.BatchNorm1d (layers.py:709, 887, 1082 apply the
+    module to the channel axis of the fused aggregate + linear output; the ReLU follows at :721, :901, :1094)."""
+    _floats(z=z)
+    if bn.weight is None:
+        raise RuntimeError('bn_act: BatchNorm without affine parameters is not covered')
+    use_batch = training or bn.running_mean is None
+    if training and bn.running_mean is not None:
+        count_batch(bn)
+    momentum = 0.1 if bn.momentum is None else bn.momentum
+    return _BNAct.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, momentum, use_batch, act)
+
+
 # --------------------------------------------------------------------------------------------------
 # fused forward of the PCFLayer edge graph (csrc/edge_chain.hip) + aggregate; backward layer by layer
 # --------------------------------------------------------------------------------------------------

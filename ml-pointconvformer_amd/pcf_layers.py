@@ -408,14 +408,16 @@ class _ConvTail(pcf_fused.CounterScope):
                 else nn.Linear(in_features, out_features)
 
     def _aggregate_linear(self, feats, nei_inds, weights, additional, inv_neighbors, inv_k, inv_idx):
+        """relu(BN(linear(aggregate))): the ReLU every caller applies (layers.py:721, 901, 1094) rides in the
+        BatchNorm kernel."""
         feats, weights = feats.contiguous(), weights.contiguous()
         additional = None if additional is None else additional.contiguous()
         if self.cfg.PCONV_OPT:
             y = self.pconv_linear_opt(feats, nei_inds, inv_neighbors, inv_k, inv_idx, weights, additional)
             if self.cfg.BATCH_NORM:
-                y = self.bn(y.reshape(-1, y.shape[-1])).view(y.shape)
-            return y
-        return self.linear(PConv.forward(feats, nei_inds, weights, additional))
+                return pcf_fused.bn_act(y, self.bn, pcf_fused.ACT_RELU, self.training)
+            return F.relu(y)
+        return _linear_act(self.linear, PConv.forward(feats, nei_inds, weights, additional), pcf_fused.ACT_RELU)
 
 
 class PointConvStridePE(_ConvTail):
@@ -449,7 +451,7 @@ class PointConvStridePE(_ConvTail):
             rel, _ = pcf_fused.edge_geometry(dense_xyz, None, nei_inds, ctr_xyz, None)
         feat_pe = self.pe_convs(rel)
         weights = self.weightnet(wn_in)
-        y = F.relu(self._aggregate_linear(feats_x, nei_inds, weights, feat_pe, inv_neighbors, inv_k, inv_idx))
+        y = self._aggregate_linear(feats_x, nei_inds, weights, feat_pe, inv_neighbors, inv_k, inv_idx)
         sparse_feats = pcf_fused.gather_max(dense_feats, nei_inds) if strided else dense_feats
         shortcut = self.unary_shortcut(sparse_feats)
         return self.unary2.forward_residual(self.dropout(y), shortcut, pcf_fused.ACT_LEAKY), wn_in
@@ -477,7 +479,7 @@ class PointConv(_ConvTail):
         weights = self.weightnet(wn_in)
         additional = wn_in if self.cfg.USE_PE else None
         y = self._aggregate_linear(dense_feats, nei_inds, weights, additional, inv_neighbors, inv_k, inv_idx)
-        return self.dropout(F.relu(y)), wn_in
+        return self.dropout(y), wn_in
 
 
 class PointConvTransposePE(_ConvTail):
@@ -513,7 +515,7 @@ class PointConvTransposePE(_ConvTail):
                 rel, _ = pcf_fused.edge_geometry(sparse_xyz, None, nei_inds, dense_xyz, None)
             feat_pe = self.pe_convs(rel)
         weights = self.weightnet(wn_in)
-        y = F.relu(self._aggregate_linear(sparse_feats, nei_inds, weights, feat_pe, inv_neighbors, inv_k, inv_idx))
+        y = self._aggregate_linear(sparse_feats, nei_inds, weights, feat_pe, inv_neighbors, inv_k, inv_idx)
         if dense_feats is not None:
             y = y + dense_feats
         y = self.dropout(y)

@@ -466,6 +466,41 @@ def test_wide_linear_bn_act_against_torch(device, rows, cin, cout, act, bn, trai
         torch.testing.assert_close(bn_d.running_var.cpu(), ref_bn.running_var.float(), rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize('rows,C,act,training', [(1408, 512, 1, True), (40, 320, 1, True), (30000, 64, 1, True),
+                                                 (5000, 192, 2, True), (777, 70, 1, False), (17, 3, 0, True)])
+def test_bn_act_against_torch(device, rows, C, act, training):
+    """Stand-alone act(BatchNorm1d(z)) (the BN + ReLU behind the fused aggregate + linear, layers.py:709/721) vs torch
+    fp64: output, dz, dgamma, dbeta, running statistics, batch counter.  The shapes cover short-and-wide matrices
+    (row ranges x column chunks of the reduction grid), columns that are not a multiple of 4, and inference."""
+    import copy
+    import pcf_fused
+    g = torch.Generator().manual_seed(rows + C)
+    z = torch.randn(2, rows, C, generator=g) * (torch.rand(C, generator=g) + 0.5) + torch.randn(C, generator=g)
+    bnm = torch.nn.BatchNorm1d(C)
+    with torch.no_grad():
+        bnm.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        bnm.bias.copy_(torch.randn(C, generator=g) * 0.2)
+        bnm.running_var.copy_(torch.rand(C, generator=g) + 0.5)
+    bn_d, ref_bn = copy.deepcopy(bnm).to(device).train(training), copy.deepcopy(bnm).double().train(training)
+    actf = {0: lambda t: t, 1: torch.relu, 2: lambda t: torch.nn.functional.leaky_relu(t, 0.1)}[act]
+    zr = z.double().requires_grad_(True)
+    want = actf(ref_bn(zr.reshape(-1, C)).view(zr.shape))
+    up = torch.randn(want.shape, generator=g)
+    want.backward(up.double())
+    zd = z.to(device).requires_grad_(True)
+    got = pcf_fused.bn_act(zd, bn_d, act, training)
+    got.backward(up.to(device))
+    tol = dict(rtol=3e-4, atol=3e-4)
+    torch.testing.assert_close(got.cpu(), want.float(), **tol)
+    torch.testing.assert_close(zd.grad.cpu(), zr.grad.float(), **tol)
+    sc = max(1.0, float(ref_bn.weight.grad.abs().max()))
+    torch.testing.assert_close(bn_d.weight.grad.cpu(), ref_bn.weight.grad.float(), rtol=3e-4, atol=3e-4 * sc)
+    torch.testing.assert_close(bn_d.bias.grad.cpu(), ref_bn.bias.grad.float(), rtol=3e-4, atol=3e-4 * sc)
+    torch.testing.assert_close(bn_d.running_mean.cpu(), ref_bn.running_mean.float(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(bn_d.running_var.cpu(), ref_bn.running_var.float(), rtol=1e-5, atol=1e-6)
+    assert int(bn_d.num_batches_tracked) == int(ref_bn.num_batches_tracked)
+
+
 @pytest.mark.parametrize('rows,cin,cout,act,bn,training', [(5000, 32, 64, 2, True, True), (999, 128, 256, 2, True, True),
                                                           (640, 96, 70, 1, False, True), (300, 160, 64, 2, True, False)])
 def test_wide_linear_bn_act_with_residual(device, rows, cin, cout, act, bn, training):
