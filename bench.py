@@ -124,7 +124,7 @@ def bench_train(args):
     torch.manual_seed(1)
     net = pcf_model.PointConvFormer_Segmentation(cfg).to(dev).train()
     model = pcf_dist.wrap_ddp(net, dev)
-    opt = torch.optim.AdamW(net.parameters(), lr=cfg.learning_rate, weight_decay=cfg.adamw_decay)
+    opt = pcf_train.make_optimizer(cfg, net)
     crit = torch.nn.CrossEntropyLoss(ignore_index=cfg.ignore_label, label_smoothing=cfg.label_smoothing).to(dev)
     # a small pool of distinct packed batches, rotated, so the kNN / CSR work is real every step
     pool = []

@@ -371,6 +371,202 @@ __global__ __launch_bounds__(BLOCK) void csr_reduce_kernel(const float* __restri
     }
 }
 
+
+// ---- C_mid = 1, unguided: the decoder's PointConvTransposePE (mid_dim_back = 1, Ci 128..384) ---------------
+// out[n, c] = sum_k w[n,k] * T[n,k,c] is a weighted sum of K rows and its backward two more of the same shape, so
+// nothing is staged in LDS: one wave per output point, one lane per 16-byte quad of the row, the K row loads of a
+// point all in flight at once (the generic kernels above run one lane per (k, m) pair = 16 of 64 lanes here).
+template <bool AL>
+__device__ __forceinline__ float4 ldq(const float* p) {
+    if (AL) return ld4(p);
+    return make_float4(p[0], p[1], p[2], p[3]);
+}
+template <bool AL>
+__device__ __forceinline__ void stq(float* p, float4 v) {
+    if (AL) { st4(p, v); return; }
+    p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
+}
+__device__ __forceinline__ float lane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = WAVE / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+    return v;
+}
+
+// neighbour rows (-1 = skip) and weights of point n, one per lane k < K <= 64
+__device__ __forceinline__ void agg1_point(const AggArgs& a, int n, int lane, int& row, float& wk) {
+    row = -1; wk = 0.f;
+    if (lane < a.K) {
+        const int b = n / a.Nout;
+        const int64_t j = a.idx[(size_t)n * a.K + lane];
+        if (j >= 0 && j < a.N) row = (int)((int64_t)b * a.N + j);
+        wk = a.w[(size_t)n * a.K + lane];
+    }
+}
+
+template <bool AL>
+__global__ __launch_bounds__(BLOCK) void agg1_fwd_kernel(const AggArgs a) {
+    const int lane = lane_id();
+    const int K = a.K, Ci = a.Ci, Ca = a.Ca, CT = Ci + Ca, Q = CT >> 2, QI = Ci >> 2;
+    for (int n = blockIdx.x * NWAVE + wave_id(); n < a.total; n += gridDim.x * NWAVE) {
+        int row; float wk;
+        agg1_point(a, n, lane, row, wk);
+        for (int q0 = 0; q0 < Q; q0 += WAVE) {
+            const int q = q0 + lane;
+            const bool gathered = q < QI, appended = !gathered && q < Q;
+            const float* ap = a.add + (size_t)n * K * Ca + (appended ? (q - QI) * 4 : 0);
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k0 = 0; k0 < K; k0 += 8) {          // eight rows in flight (lanes >= K hold row -1, weight 0)
+                float4 v[8];
+                float wv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int k = min(k0 + u, WAVE - 1);
+                    const int r = __builtin_amdgcn_readlane(row, k);
+                    wv[u] = lane_f(wk, k);
+                    v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (gathered) { if (r >= 0) v[u] = ldq<AL>(a.x + (size_t)r * Ci + q * 4); }
+                    else if (appended && k0 + u < K) v[u] = ldq<AL>(ap + (size_t)k * Ca);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc = fma4(wv[u], v[u], acc);
+            }
+            if (q < Q) stq<AL>(a.out + (size_t)n * CT + q * 4, acc);
+        }
+    }
+}
+
+// grad_w[n,k] = <gout[n,:], T[n,k,:]>, grad_add[n,k,:] = w[n,k] * gout[n, Ci:], and for ATOMIC the scatter
+// grad_x[idx[n,k], :] += w[n,k] * gout[n, :Ci]; otherwise grad_x comes from csr_gather1_kernel below.
+// NP = 64-lane passes over the quads of a row (CT <= 256 * NP).
+template <bool AL, bool ATOMIC, int NP>
+__global__ __launch_bounds__(BLOCK) void agg1_bwd_kernel(const AggArgs a) {
+    const int lane = lane_id();
+    const int K = a.K, Ci = a.Ci, Ca = a.Ca, CT = Ci + Ca, Q = CT >> 2, QI = Ci >> 2;
+    for (int n = blockIdx.x * NWAVE + wave_id(); n < a.total; n += gridDim.x * NWAVE) {
+        int row; float wk;
+        agg1_point(a, n, lane, row, wk);
+        float4 g[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int q = p * WAVE + lane;
+            g[p] = q < Q ? ldq<AL>(a.gout + (size_t)n * CT + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float mine = 0.f;
+        for (int k0 = 0; k0 < K; k0 += 4) {              // four rows in flight (lanes >= K hold row -1, weight 0)
+            float part[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = min(k0 + u, WAVE - 1);
+                const int r = __builtin_amdgcn_readlane(row, k);
+                const float wv = lane_f(wk, k);
+                part[u] = 0.f;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const int q = p * WAVE + lane;
+                    if (q < QI) {
+                        if (r >= 0) {
+                            part[u] = dot4(g[p], ldq<AL>(a.x + (size_t)r * Ci + q * 4), part[u]);
+                            if (ATOMIC) {
+                                float* dst = a.gx + (size_t)r * Ci + q * 4;
+                                atomicAdd(dst + 0, wv * g[p].x); atomicAdd(dst + 1, wv * g[p].y);
+                                atomicAdd(dst + 2, wv * g[p].z); atomicAdd(dst + 3, wv * g[p].w);
+                            }
+                        }
+                    } else if (q < Q && k0 + u < K) {
+                        const size_t o = ((size_t)n * K + k) * Ca + (q - QI) * 4;
+                        part[u] = dot4(g[p], ldq<AL>(a.add + o), part[u]);
+                        stq<AL>(a.gadd + o, make_float4(wv * g[p].x, wv * g[p].y, wv * g[p].z, wv * g[p].w));
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float t = wave_sum(part[u]);
+                if (lane == k0 + u) mine = t;
+            }
+        }
+        if (lane < K) a.gw[(size_t)n * K + lane] = mine;
+    }
+}
+
+// grad_x[r, :] = sum over the inverse list of input row r of w[n,k] * dout[n, :Ci]  (C_mid = 1): the rows of the
+// aggregate's output gradient [total, J] are gathered directly -- no per-edge contribution rows are written and read
+// back (2 x E x Ci x 4 B at the finest level = 2.4 GB per layer).  One wave per input row; 64 list entries' (n, k, w)
+// are fetched by the lanes at once, then lane groups of LPE lanes walk alternate entries in a fixed order
+// (deterministic) and are summed by xor-shuffles.  Stands in for input_only_backward_kernel (pconv_ops.cu:539-619).
+template <bool AL, int NP>
+__global__ __launch_bounds__(BLOCK) void csr_gather1_kernel(const float* __restrict__ dout, const float* __restrict__ w,
+                                                            const int32_t* __restrict__ inv_n,
+                                                            const uint8_t* __restrict__ inv_k,
+                                                            const int32_t* __restrict__ inv_idx, float* __restrict__ gx,
+                                                            int B, int N, int Nout, int K, int Ci, int J, int inv_len,
+                                                            int inv_idx_len) {
+    const int lane = lane_id();
+    const int QI = Ci >> 2;
+    const int LPE = QI >= WAVE ? WAVE : pow2_ceil_dev(QI);     // lanes per list entry
+    const int G = WAVE / LPE;
+    const int cl = lane & (LPE - 1), eg = lane / LPE;
+    const long long rows = (long long)B * N;
+    for (long long r = (long long)blockIdx.x * NWAVE + wave_id(); r < rows; r += (long long)gridDim.x * NWAVE) {
+        const int b = (int)(r / N);
+        const int p = (int)(r - (long long)b * N);
+        int beg = inv_idx[(size_t)b * inv_idx_len + p];
+        int end = inv_idx[(size_t)b * inv_idx_len + p + 1];
+        beg = max(0, min(beg, inv_len));
+        end = max(beg, min(end, inv_len));
+        const int32_t* ln = inv_n + (size_t)b * inv_len;
+        const uint8_t* lk = inv_k + (size_t)b * inv_len;
+        float4 acc[NP];
+#pragma unroll
+        for (int u = 0; u < NP; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int base = beg; base < end; base += WAVE) {
+            const int j = base + lane;
+            int erow = -1;
+            float ew = 0.f;
+            if (j < end) {
+                const int n = ln[j];
+                const int k = lk[j];
+                if (n >= 0 && n < Nout && k < K) {
+                    erow = b * Nout + n;
+                    ew = w[(size_t)erow * K + k];
+                }
+            }
+            const int cnt = min(WAVE, end - base);
+            for (int e0 = 0; e0 < cnt; e0 += 4 * G) {    // uniform trip count: every lane reaches the shuffles
+                int rr[4];
+                float ww[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {                // four rows in flight per lane group
+                    const int e = e0 + t * G + eg;
+                    rr[t] = __shfl(erow, e & (WAVE - 1), WAVE);
+                    ww[t] = __shfl(ew, e & (WAVE - 1), WAVE);
+                    if (e >= cnt) rr[t] = -1;
+                }
+#pragma unroll
+                for (int u = 0; u < NP; ++u) {
+                    const int q = u * WAVE + cl;
+                    float4 v[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        v[t] = (q < QI && rr[t] >= 0) ? ldq<AL>(dout + (size_t)rr[t] * J + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[u] = fma4(ww[t], v[t], acc[u]);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            for (int off = LPE; off < WAVE; off <<= 1) {
+                acc[u].x += __shfl_xor(acc[u].x, off, WAVE); acc[u].y += __shfl_xor(acc[u].y, off, WAVE);
+                acc[u].z += __shfl_xor(acc[u].z, off, WAVE); acc[u].w += __shfl_xor(acc[u].w, off, WAVE);
+            }
+            const int q = u * WAVE + cl;
+            if (eg == 0 && q < QI) stq<AL>(gx + (size_t)r * Ci + q * 4, acc[u]);
+        }
+    }
+}
+
 // ---- host side ----------------------------------------------------------------------------------
 static int pow2_ceil(int v) {
     int p = 1;
@@ -484,6 +680,12 @@ static int launch_bwd_mode(const AggArgs& a, const Plan& pl, hipStream_t s) {
 #undef PCF_BWD
 }
 
+// C_mid = 1 without guidance, rows of whole 16-byte quads, K one-per-lane: the LDS-free kernels.
+bool agg1_covers(bool guided, int K, int Ci, int Ca, int Cm) {
+    return !guided && Cm == 1 && K <= WAVE && Ci % 4 == 0 && Ca % 4 == 0 && Ci + Ca <= 2 * 4 * WAVE;
+}
+static int agg1_grid(int total) { return (int)std::min<long long>(ceil_div(total, NWAVE), 256 * 64); }
+
 static int check_dims(const char* who, int B, int N, int Nout, int K, int Ci, int Ca, int Cm, int H, bool guided) {
     PCF_REQUIRE(B >= 0 && N >= 0 && Nout >= 0, "%s: negative batch/point count (B=%d N=%d Nout=%d)", who, B, N, Nout);
     PCF_REQUIRE(K >= 1 && Ci >= 0 && Ca >= 0 && Ci + Ca >= 1 && Cm >= 1, "%s: bad K/Ci/Ca/Cm (%d/%d/%d/%d)", who, K, Ci,
@@ -505,18 +707,32 @@ int aggregate_forward(const float* x, const int64_t* idx, const float* guid, con
                 (const void*)w, (void*)out);
     PCF_REQUIRE(Ca == 0 || add, "aggregate forward: Ca=%d but additional features pointer is null", Ca);
     const bool al = aligned16(x) && aligned16(w) && aligned16(out) && (Ca == 0 || aligned16(add));
-    Plan pl;
-    if (int e = make_plan(pl, false, guid != nullptr, total, K, Ci, Ca, Cm, H, al)) return e;
     AggArgs a{};
     a.x = x; a.idx = idx; a.guid = guid; a.w = w; a.add = add; a.out = out;
     a.total = total; a.N = N; a.Nout = Nout; a.K = K; a.Ci = Ci; a.Ca = Ca; a.Cm = Cm; a.H = guid ? H : 1;
+    if (agg1_covers(guid != nullptr, K, Ci, Ca, Cm)) {
+        if (al) hipLaunchKernelGGL(agg1_fwd_kernel<true>, dim3(agg1_grid(total)), dim3(BLOCK), 0, stream, a);
+        else hipLaunchKernelGGL(agg1_fwd_kernel<false>, dim3(agg1_grid(total)), dim3(BLOCK), 0, stream, a);
+        return check_launch("aggregate forward (C_mid = 1)");
+    }
+    Plan pl;
+    if (int e = make_plan(pl, false, guid != nullptr, total, K, Ci, Ca, Cm, H, al)) return e;
     a.P = pl.P; a.TS = pl.TS; a.GS = pl.GS;
     a.offG = pl.offG; a.offT = pl.offT; a.offD = pl.offD; a.offW = pl.offW; a.offO = pl.offO;
     return launch_fwd(a, pl, stream);
 }
 
+template <bool AL, bool ATOMIC>
+static int launch_agg1_bwd(const AggArgs& a, hipStream_t s) {
+    const dim3 grid(agg1_grid(a.total));
+    if (a.Ci + a.Ca <= 4 * WAVE) hipLaunchKernelGGL((agg1_bwd_kernel<AL, ATOMIC, 1>), grid, dim3(BLOCK), 0, s, a);
+    else hipLaunchKernelGGL((agg1_bwd_kernel<AL, ATOMIC, 2>), grid, dim3(BLOCK), 0, s, a);
+    return check_launch("aggregate backward (C_mid = 1)");
+}
+
 // Backward of both operators.  Exactly one of gx (atomic scatter; zeroed here) / contrib (per-edge
-// rows for csr_reduce) is non-null.
+// rows for csr_reduce) is non-null -- or neither where agg1_covers() holds and the caller takes grad_x from
+// csr_gather1().
 int aggregate_backward(const float* gout, const float* x, const int64_t* idx, const float* guid, const float* w,
                        const float* add, float* gx, float* contrib, float* gguid, float* gw, float* gadd, int B,
                        int N, int Nout, int K, int Ci, int Ca, int Cm, int H, hipStream_t stream) {
@@ -528,16 +744,23 @@ int aggregate_backward(const float* gout, const float* x, const int64_t* idx, co
     }
     if (total == 0) return ok();
     PCF_REQUIRE(gout && idx && w && gw, "aggregate backward: null pointer");
-    PCF_REQUIRE((gx != nullptr) != (contrib != nullptr) || Ci == 0, "aggregate backward: need exactly one of grad_x / contrib");
+    const bool cm1 = agg1_covers(guid != nullptr, K, Ci, Ca, Cm) && !contrib;
+    PCF_REQUIRE((gx != nullptr) != (contrib != nullptr) || Ci == 0 || (cm1 && !gx),
+                "aggregate backward: need exactly one of grad_x / contrib");
     PCF_REQUIRE(!guid || gguid, "aggregate backward: grad_guid is null");
     PCF_REQUIRE(Ca == 0 || (add && gadd), "aggregate backward: Ca=%d but add/grad_add pointer is null", Ca);
     const bool al = aligned16(x) && aligned16(w) && aligned16(gout) && aligned16(gw) && (Ca == 0 || aligned16(add));
-    Plan pl;
-    if (int e = make_plan(pl, true, guid != nullptr, total, K, Ci, Ca, Cm, H, al)) return e;
     AggArgs a{};
     a.x = x; a.idx = idx; a.guid = guid; a.w = w; a.add = add; a.gout = gout;
     a.gx = gx; a.contrib = contrib; a.gguid = gguid; a.gw = gw; a.gadd = gadd;
     a.total = total; a.N = N; a.Nout = Nout; a.K = K; a.Ci = Ci; a.Ca = Ca; a.Cm = Cm; a.H = guid ? H : 1;
+    if (cm1) {
+        const bool al1 = al && (Ca == 0 || aligned16(gadd));
+        if (gx) return al1 ? launch_agg1_bwd<true, true>(a, stream) : launch_agg1_bwd<false, true>(a, stream);
+        return al1 ? launch_agg1_bwd<true, false>(a, stream) : launch_agg1_bwd<false, false>(a, stream);
+    }
+    Plan pl;
+    if (int e = make_plan(pl, true, guid != nullptr, total, K, Ci, Ca, Cm, H, al)) return e;
     a.P = pl.P; a.TS = pl.TS; a.GS = pl.GS;
     a.offG = pl.offG; a.offT = pl.offT; a.offD = pl.offD; a.offW = pl.offW; a.offO = pl.offO;
     return gx ? launch_bwd_mode<true>(a, pl, stream) : launch_bwd_mode<false>(a, pl, stream);
@@ -551,6 +774,23 @@ int csr_reduce(const float* contrib, const int32_t* inv_n, const uint8_t* inv_k,
     hipLaunchKernelGGL(csr_reduce_kernel, dim3(grid), dim3(BLOCK), 0, stream, contrib, inv_n, inv_k, inv_idx, gx, B, N,
                        Nout, K, Ci, inv_len, inv_idx_len);
     return check_launch("csr gather-reduce");
+}
+
+// grad_x of the C_mid = 1 aggregate straight from its output gradient dout [B*Nout, J] (J = Ci + Ca) and the CSR.
+int csr_gather1(const float* dout, const float* w, const int32_t* inv_n, const uint8_t* inv_k, const int32_t* inv_idx,
+                float* gx, int B, int N, int Nout, int K, int Ci, int J, int inv_len, int inv_idx_len,
+                hipStream_t stream) {
+    const long long rows = (long long)B * N;
+    if (rows == 0 || Ci == 0) return ok();
+    const dim3 grid((unsigned)std::min<long long>((rows + NWAVE - 1) / NWAVE, 256 * 64));
+    const bool al = aligned16(dout) && aligned16(gx) && J % 4 == 0;
+#define PCF_G1(ALV, NPV)                                                                                            \
+    hipLaunchKernelGGL((csr_gather1_kernel<ALV, NPV>), grid, dim3(BLOCK), 0, stream, dout, w, inv_n, inv_k, inv_idx, gx, \
+                       B, N, Nout, K, Ci, J, inv_len, inv_idx_len)
+    if (Ci <= 4 * WAVE) { if (al) PCF_G1(true, 1); else PCF_G1(false, 1); }
+    else { if (al) PCF_G1(true, 2); else PCF_G1(false, 2); }
+#undef PCF_G1
+    return check_launch("csr gather (C_mid = 1)");
 }
 
 }  // namespace pcf

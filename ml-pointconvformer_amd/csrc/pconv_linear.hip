@@ -11,6 +11,9 @@ int aggregate_backward(const float*, const float*, const int64_t*, const float*,
                        float*, float*, float*, float*, int, int, int, int, int, int, int, int, hipStream_t);
 int csr_reduce(const float*, const int32_t*, const uint8_t*, const int32_t*, float*, int, int, int, int, int, int, int,
                hipStream_t);
+int csr_gather1(const float*, const float*, const int32_t*, const uint8_t*, const int32_t*, float*, int, int, int, int,
+                int, int, int, int, hipStream_t);
+bool agg1_covers(bool, int, int, int, int);
 int gemm_f32(const float*, bool, int, const float*, bool, int, const float*, float*, int, int, int, int, int, hipStream_t);
 int choose_splits(int, int, int);
 int slab_sum(const float*, float*, long long, int, hipStream_t);
@@ -31,6 +34,7 @@ static BwdWorkspace plan_ws(int B, int N, int Nout, int K, int Ci, int Ca, int C
     w.off_dpcv = off; off = align_up(off + total * J * 4, 256);
     w.off_slabs = off; off = align_up(off + (w.splits > 1 ? (size_t)w.splits * Co * J * 4 : 0), 256);
     w.off_part = off; off = align_up(off + (size_t)colsum_blocks((int)total) * Co * 4, 256);
+    if (agg1_covers(false, K, Ci, Ca, Cm)) with_contrib = false;      // grad_x is gathered from d(pconv_out)
     w.off_contrib = off; off = align_up(off + (with_contrib ? total * K * Ci * 4 : 0), 256);
     w.bytes = off;
     return w;
@@ -137,6 +141,14 @@ int pcf_hip_pconv_linear_opt_backward(const float* grad_out, const float* x, con
     PCF_REQUIRE(grad_out && lin_w && pconv_out, "pconv_linear_opt_backward: null pointer");
     if (int e = linear_backward_common(grad_out, lin_w, pconv_out, grad_lin_w, grad_lin_b, wsp, ws, total, J, Co, s))
         return e;
+    if (Ci > 0 && agg1_covers(false, K, Ci, Ca, Cm)) {
+        // C_mid = 1 (the decoder): grad_x gathers rows of d(pconv_out) through the CSR, no per-edge rows in between
+        const float* dpcv = reinterpret_cast<const float*>(wsp + ws.off_dpcv);
+        if (int e = aggregate_backward(dpcv, x, idx, nullptr, w, add, nullptr, nullptr, nullptr, grad_w, grad_add, B, N,
+                                       Nout, K, Ci, Ca, Cm, 1, s))
+            return e;
+        return csr_gather1(dpcv, w, inv_neighbors, inv_k, inv_idx, grad_x, B, N, Nout, K, Ci, J, inv_len, inv_idx_len, s);
+    }
     float* contrib = reinterpret_cast<float*>(wsp + ws.off_contrib);
     if (Ci == 0) contrib = nullptr;
     if (int e = aggregate_backward(reinterpret_cast<const float*>(wsp + ws.off_dpcv), x, idx, nullptr, w, add, nullptr,

@@ -105,8 +105,30 @@ def _ptr(t):
     return None if t is None or t.numel() == 0 else t.data_ptr()
 
 
+_raw_stream = torch._C._cuda_getCurrentRawStream
+_exchange_device = torch.cuda._exchange_device
+_maybe_exchange_device = torch.cuda._maybe_exchange_device
+
+
 def _stream(dev):
-    return torch.cuda.current_stream(dev).cuda_stream
+    """torch's current HIP stream of `dev` as a raw handle (a training iteration asks ~400 times: the Stream object
+    route costs 5 us per call, this one 0.3)."""
+    return _raw_stream(dev.index if dev.index is not None else torch.cuda.current_device())
+
+
+class _guard:
+    """`with torch.cuda.device(dev)` without its Python-side index parsing (2 us per use, ~450 uses per iteration)."""
+    __slots__ = ('idx', 'prev')
+
+    def __init__(self, dev):
+        self.idx = -1 if dev.index is None else dev.index
+
+    def __enter__(self):
+        self.prev = _exchange_device(self.idx)
+
+    def __exit__(self, *exc):
+        _maybe_exchange_device(self.prev)
+        return False
 
 
 _timeline = None   # when a list: (entry point name, start event, end event) per bracketed C-ABI call
@@ -166,7 +188,7 @@ def pcf_forward(input, neighbor_inds, guidance, weights):
     H = guidance.shape[3]
     dev = _same_device(input, neighbor_inds, guidance, weights)
     out = torch.empty(B, Nout, Ci * Cm, dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _guard(dev):
         _call(_pcf_fwd, _ptr(input), _ptr(neighbor_inds), _ptr(guidance), _ptr(weights), _ptr(out),
               B, N, Nout, K, Ci, Cm, H, _stream(dev))
     return out
@@ -184,7 +206,7 @@ def pcf_backward(grad_output, input, neighbor_inds, guidance, weights):
     grad_input = torch.empty_like(input)
     grad_guidance = torch.empty_like(guidance)
     grad_weights = torch.empty_like(weights)
-    with torch.cuda.device(dev):
+    with _guard(dev):
         _call(_pcf_bwd, _ptr(grad_output), _ptr(input), _ptr(neighbor_inds), _ptr(guidance), _ptr(weights),
               _ptr(grad_input), _ptr(grad_guidance), _ptr(grad_weights), B, N, Nout, K, Ci, Cm, H, _stream(dev))
     return [grad_input, grad_guidance, grad_weights]
@@ -209,7 +231,7 @@ def pcf_backward_csr(grad_output, input, inverse_neighbor, inverse_neighbor_k, i
     grad_weights = torch.empty_like(weights)
     nbytes = _pcf_bwd_csr_ws(B, Nout, K, Ci)
     ws = _workspace(nbytes, dev)
-    with torch.cuda.device(dev):
+    with _guard(dev):
         _call(_pcf_bwd_csr, _ptr(grad_output), _ptr(input), _ptr(inverse_neighbor), _ptr(inverse_neighbor_k),
               _ptr(inverse_neighbor_idx), _ptr(neighbor_inds), _ptr(guidance), _ptr(weights), _ptr(grad_input),
               _ptr(grad_guidance), _ptr(grad_weights), ws.data_ptr(), nbytes, B, N, Nout, K, Ci, Cm, H,
@@ -231,7 +253,7 @@ def pconv_forward(input, neighbor_inds, weights, additional_features):
     Ca = _add_dims(additional_features, B, Nout, K)
     dev = _same_device(input, neighbor_inds, weights, additional_features)
     out = torch.empty(B, Nout, (Ci + Ca) * Cm, dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _guard(dev):
         _call(_pconv_fwd, _ptr(input), _ptr(neighbor_inds), _ptr(weights), _ptr(additional_features), _ptr(out),
               B, N, Nout, K, Ci, Ca, Cm, _stream(dev))
     return out
@@ -248,7 +270,7 @@ def pconv_backward(grad_output, input, neighbor_inds, weights, additional_featur
     grad_input = torch.empty_like(input)
     grad_weights = torch.empty_like(weights)
     grad_additional = torch.empty_like(additional_features)
-    with torch.cuda.device(dev):
+    with _guard(dev):
         _call(_pconv_bwd, _ptr(grad_output), _ptr(input), _ptr(neighbor_inds), _ptr(weights),
               _ptr(additional_features), _ptr(grad_input), _ptr(grad_weights), _ptr(grad_additional),
               B, N, Nout, K, Ci, Ca, Cm, _stream(dev))
@@ -274,7 +296,7 @@ def pconv_linear_forward(input, neighbor_inds, weights, additional_features, lin
     dev = _same_device(input, neighbor_inds, weights, additional_features, linear_weights, linear_bias)
     out = torch.empty(B, Nout, Co, dtype=torch.float32, device=dev)
     pconv_out = torch.empty(B, Nout, (Ci + Ca) * Cm, dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _guard(dev):
         _call(_pl_fwd, _ptr(input), _ptr(neighbor_inds), _ptr(weights), _ptr(additional_features),
               _ptr(linear_weights), _ptr(linear_bias), _ptr(out), _ptr(pconv_out),
               B, N, Nout, K, Ci, Ca, Cm, Co, _stream(dev))
@@ -308,7 +330,7 @@ def pconv_linear_backward(grad_output, input, neighbor_inds, weights, additional
     grad_linear_bias = torch.empty(Co, dtype=torch.float32, device=dev)
     nbytes = _pl_bwd_ws(B, N, Nout, K, Ci, Ca, Cm, Co)
     ws = _workspace(nbytes, dev)
-    with torch.cuda.device(dev):
+    with _guard(dev):
         _call(_pl_bwd, _ptr(grad_output), _ptr(input), _ptr(neighbor_inds), _ptr(weights), _ptr(additional_features),
               _ptr(linear_weights), _ptr(pconv_output), _ptr(grad_input), _ptr(grad_weights), _ptr(grad_additional),
               _ptr(grad_linear_weights), _ptr(grad_linear_bias), ws.data_ptr(), nbytes,
@@ -342,7 +364,7 @@ def pconv_linear_opt_backward(grad_output, input, inverse_neighbor, inverse_neig
     grad_linear_bias = torch.empty(Co, dtype=torch.float32, device=dev)
     nbytes = _plo_bwd_ws(B, N, Nout, K, Ci, Ca, Cm, Co)
     ws = _workspace(nbytes, dev)
-    with torch.cuda.device(dev):
+    with _guard(dev):
         _call(_plo_bwd, _ptr(grad_output), _ptr(input), _ptr(inverse_neighbor), _ptr(inverse_neighbor_k),
               _ptr(inverse_neighbor_idx), _ptr(neighbor_inds), _ptr(weights), _ptr(additional_features),
               _ptr(linear_weights), _ptr(pconv_output), _ptr(grad_input), _ptr(grad_weights), _ptr(grad_additional),
@@ -364,7 +386,7 @@ def compute_knn_inverse(neighbor_inds, total_points):
     inv_idx = torch.empty(B, total_points + 1, dtype=torch.int32, device=dev)
     nbytes = _inv_ws(B, Nq, K, total_points)
     ws = _workspace(nbytes, dev)
-    with torch.cuda.device(dev):
+    with _guard(dev):
         _call(_inv, _ptr(neighbor_inds), _ptr(inv_neighbors), _ptr(inv_k), inv_idx.data_ptr(), ws.data_ptr(), nbytes,
               B, Nq, K, total_points, _stream(dev))
     return [inv_neighbors, inv_k, inv_idx]
@@ -396,7 +418,7 @@ def knn_packed(ref, query, ref_offsets, query_offsets, K, method='auto'):
         raise ValueError(f'knn_packed: unknown method {method!r}')
     n_ref, n_query = ref.shape[0], query.shape[0]
     use_grid = method == 'grid' or (method == 'auto' and n_ref >= KNN_GRID_MIN_REFS)
-    with torch.cuda.device(dev):
+    with _guard(dev):
         if use_grid:
             nbytes = _knn_grid_ws(n_ref, S)
             ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=dev)
@@ -417,6 +439,6 @@ def gemm_nt(a, b, bias=None):
     M, Kd = a.shape
     N = b.shape[0]
     out = torch.empty(M, N, dtype=torch.float32, device=a.device)
-    with torch.cuda.device(a.device):
+    with _guard(a.device):
         _call(_gemm_nt, _ptr(a), _ptr(b), _ptr(bias), _ptr(out), M, N, Kd, _stream(a.device))
     return out

@@ -8,7 +8,7 @@ import ctypes
 import torch
 
 import pcf_cuda
-from pcf_cuda import _P, _I, _check_input, _floats, _lib, _ptr, _stream
+from pcf_cuda import _P, _I, _check_input, _floats, _guard, _lib, _ptr, _stream
 
 
 def _call(fn, *args):
@@ -77,7 +77,7 @@ class _GatherRows(torch.autograd.Function):
         B, N, C = table.shape
         S = idx[0].numel()
         out = torch.empty(*idx.shape, C, dtype=table.dtype, device=table.device)
-        with torch.cuda.device(table.device):
+        with _guard(table.device):
             _call(_gather_rows, _ptr(table), _ptr(idx), _ptr(out), B, N, S, C, _stream(table.device))
         ctx.save_for_backward(idx)
         ctx.dims = (B, N, S, C)
@@ -89,7 +89,7 @@ class _GatherRows(torch.autograd.Function):
         B, N, S, C = ctx.dims
         grad = grad.contiguous()
         gt = torch.empty(B, N, C, dtype=grad.dtype, device=grad.device)
-        with torch.cuda.device(grad.device):
+        with _guard(grad.device):
             _call(_scatter_add_rows, _ptr(grad), _ptr(idx), _ptr(gt), B, N, S, C, _stream(grad.device))
         return gt, None
 
@@ -110,7 +110,7 @@ class _GatherMax(torch.autograd.Function):
         _, M, K = idx.shape
         out = torch.empty(B, M, C, dtype=table.dtype, device=table.device)
         argk = torch.empty(B, M, C, dtype=torch.uint8, device=table.device)
-        with torch.cuda.device(table.device):
+        with _guard(table.device):
             _call(_gather_max, _ptr(table), _ptr(idx), _ptr(out), _ptr(argk), B, N, M, K, C, _stream(table.device))
         ctx.save_for_backward(idx, argk)
         ctx.dims = (B, N, M, K, C)
@@ -122,7 +122,7 @@ class _GatherMax(torch.autograd.Function):
         B, N, M, K, C = ctx.dims
         grad = grad.contiguous()
         gt = torch.empty(B, N, C, dtype=grad.dtype, device=grad.device)
-        with torch.cuda.device(grad.device):
+        with _guard(grad.device):
             _call(_gather_max_bwd, _ptr(grad), _ptr(idx), _ptr(argk), _ptr(gt), B, N, M, K, C, _stream(grad.device))
         return gt, None
 
@@ -151,7 +151,7 @@ def edge_geometry(ref_xyz, ref_norm, idx, ctr_xyz, ctr_norm, want_rel=True):
     dev = ref_xyz.device
     rel = torch.empty(B, M, K, 3, dtype=torch.float32, device=dev) if (want_rel or not want_vi) else None
     vi = torch.empty(B, M, K, 12, dtype=torch.float32, device=dev) if want_vi else None
-    with torch.cuda.device(dev):
+    with _guard(dev):
         _call(_edge_geometry, _ptr(ref_xyz), _ptr(ref_norm) if want_vi else None, _ptr(idx), _ptr(ctr_xyz),
               _ptr(ctr_norm) if want_vi else None, _ptr(rel), _ptr(vi), B, N, M, K, _stream(dev))
     return rel, vi
@@ -161,7 +161,7 @@ def vi_from_gathered(localized_xyz, gathered_norm, ctr_norm):
     _floats(localized_xyz=localized_xyz, gathered_norm=gathered_norm, ctr_norm=ctr_norm)
     B, M, K, _ = localized_xyz.shape
     vi = torch.empty(B, M, K, 12, dtype=torch.float32, device=localized_xyz.device)
-    with torch.cuda.device(vi.device):
+    with _guard(vi.device):
         _call(_vi_from_gathered, _ptr(localized_xyz), _ptr(gathered_norm), _ptr(ctr_norm), _ptr(vi), B, M, K,
               _stream(vi.device))
     return vi
@@ -216,7 +216,7 @@ class _LinearBNAct(torch.autograd.Function):
         extras = (_ptr(gadd), _ptr(gidx) if gadd is not None else None, rpb, gN, int(group))
         mean = rstd = None
         stream = _stream(dev)
-        with torch.cuda.device(dev):
+        with _guard(dev):
             if bn:
                 if training:
                     mean = torch.empty(Cout, dtype=torch.float32, device=dev)
@@ -252,7 +252,7 @@ class _LinearBNAct(torch.autograd.Function):
         dgadd = torch.empty_like(gadd) if gadd is not None else None
         nbytes = _rowlin_ws(Cin, Cout)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
+        with _guard(dev):
             _call(_rowlin_bwd, _ptr(x), _ptr(dy), R, Cin, _ptr(W), _ptr(b), Cout, _ptr(mean), _ptr(rstd),
                   _ptr(gamma) if bn else None, _ptr(beta) if bn else None, 1 if training else 0, act,
                   _ptr(gadd), _ptr(gidx), rpb, gN, group,
@@ -297,7 +297,7 @@ class _GuidanceDiff(torch.autograd.Function):
         dev = gx.device
         s = torch.empty(B, M, K, G + P, dtype=torch.float32, device=dev)
         argk = torch.empty(B, M, G + P, dtype=torch.uint8, device=dev) if use_max else None
-        with torch.cuda.device(dev):
+        with _guard(dev):
             _call(_gdiff_fwd, _ptr(gx), _ptr(idx), _ptr(pe), _ptr(s), _ptr(argk), B, N, M, K, G, P, 1 if use_max else 0,
                   _stream(dev))
         ctx.save_for_backward(idx, argk)
@@ -311,7 +311,7 @@ class _GuidanceDiff(torch.autograd.Function):
         ds = ds.contiguous()
         dgx = torch.empty(B, N, G, dtype=torch.float32, device=ds.device)
         dpe = torch.empty(B, M, K, P, dtype=torch.float32, device=ds.device)
-        with torch.cuda.device(ds.device):
+        with _guard(ds.device):
             _call(_gdiff_bwd, _ptr(ds), _ptr(idx), _ptr(argk), _ptr(dgx), _ptr(dpe), B, N, M, K, G, P, _stream(ds.device))
         return dgx, None, dpe, None
 
@@ -351,7 +351,7 @@ class _WideLinearBNAct(torch.autograd.Function):
         stream = _stream(dev)
         z = torch.empty(*x.shape[:-1], Cout, dtype=torch.float32, device=dev)
         mean = rstd = None
-        with torch.cuda.device(dev):
+        with _guard(dev):
             _call(_gemm_nt_c, _ptr(x), _ptr(W), _ptr(b), _ptr(z), R, Cout, Cin, stream)
             if bn and training:
                 mean = torch.empty(Cout, dtype=torch.float32, device=dev)
@@ -388,7 +388,7 @@ class _WideLinearBNAct(torch.autograd.Function):
         # it): no column sums of dz; the BN-backward finalize kernel writes the zeros
         zero_db = bn and training
         db = torch.empty(Cout, dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _guard(dev):
             if bn or act != ACT_NONE:
                 dz = torch.empty_like(z)
                 if residual is not None and ctx.needs_input_grad[11]:
@@ -442,7 +442,7 @@ class _BNAct(torch.autograd.Function):
         dev = z.device
         stream = _stream(dev)
         y = torch.empty_like(z)
-        with torch.cuda.device(dev):
+        with _guard(dev):
             if training:
                 mean = torch.empty(C, dtype=torch.float32, device=dev)
                 rstd = torch.empty(C, dtype=torch.float32, device=dev)
@@ -469,7 +469,7 @@ class _BNAct(torch.autograd.Function):
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
         nbytes = _bnact_ws(R, C)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
+        with _guard(dev):
             _call(_bnact_bwd, _ptr(z), None, _ptr(dy), R, C, _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta),
                   1 if training else 0, act, _ptr(dz), None, _ptr(dgamma), _ptr(dbeta), None, ws.data_ptr(), nbytes,
                   _stream(dev))
@@ -576,7 +576,7 @@ class _PCFChain(torch.autograd.Function):
         rm = _ptr_array([bn.running_mean for bn in bns]) if training else None
         rv = _ptr_array([bn.running_var for bn in bns]) if training else None
         mom = bns[0].momentum if bns[0].momentum is not None else 0.1
-        with torch.cuda.device(dev):
+        with _guard(dev):
             _call(_chain_fwd, _ptr(vi), _ptr(idx), _ptr(u), E, M * K, N, K, cv, g, heads, cm, _ptr_array(Ws), _ptr_array(bs),
                   _ptr_array(gammas), _ptr_array(betas), rm, rv, float(bns[0].eps), float(mom), 1 if training else 0,
                   stats.data_ptr(), _ptr(pe), _ptr(a1), _ptr(h1), _ptr(a2), _ptr(h1_acc), _ptr(a2_acc), _ptr(score), _ptr(w),
@@ -599,7 +599,7 @@ class _PCFChain(torch.autograd.Function):
         st = lambda l: (stats[l], stats[6 + l])
         if ctx.fused_backward:
             dev = dagg.device
-            with torch.cuda.device(dev):
+            with _guard(dev):
                 dfx, dscore, dw = pcf_cuda.pcf_backward(dagg.contiguous(), fx, idx, score, w)
                 du = torch.empty_like(u)
                 grads = [torch.empty_like(t) for t in keep]
@@ -611,7 +611,7 @@ class _PCFChain(torch.autograd.Function):
                       _ptr_array(betas), stats.data_ptr(), _ptr(du), _ptr_array(grads[0::4]), _ptr_array(grads[1::4]),
                       _ptr_array(grads[2::4]), _ptr_array(grads[3::4]), ws.data_ptr(), nbytes, _stream(dev))
             return (None, None, None, None, None, du, dfx, *grads)
-        with torch.cuda.device(dagg.device):
+        with _guard(dagg.device):
             dfx, dscore, dw = pcf_cuda.pcf_backward(dagg.contiguous(), fx, idx, score, w)
             L = {}
             dh1, *L[2] = _rowlin_backward_raw(h1, dscore, Ws[2], bs[2], *st(2), gammas[2], betas[2], tr, ACT_SIGMOID, True)[:5]
@@ -662,7 +662,7 @@ class _WeightNetChain(torch.autograd.Function):
         rm = _ptr_array([bn.running_mean for bn in bns]) if training else None
         rv = _ptr_array([bn.running_var for bn in bns]) if training else None
         mom = bns[0].momentum if bns[0].momentum is not None else 0.1
-        with torch.cuda.device(dev):
+        with _guard(dev):
             _call(_wn_fwd, _ptr(x), E, cin, cm, _ptr_array(Ws), _ptr_array(bs), _ptr_array(gammas), _ptr_array(betas), rm, rv,
                   float(bns[0].eps), float(mom), 1 if training else 0, stats.data_ptr(), _ptr(a2_acc), _ptr(w),
                   ws.data_ptr(), nbytes, _stream(dev))
@@ -683,7 +683,7 @@ class _WeightNetChain(torch.autograd.Function):
         grads = [torch.empty_like(t) for t in keep]
         nbytes = _chain_bwd_ws(E)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
+        with _guard(dev):
             _call(_wn_bwd, _ptr(x), _ptr(a2_acc), _ptr(dw), E, cin, Ws[2].shape[0], _ptr_array(Ws), _ptr_array(bs),
                   _ptr_array(gammas), _ptr_array(betas), stats.data_ptr(), _ptr_array(grads[0::4]), _ptr_array(grads[1::4]),
                   _ptr_array(grads[2::4]), _ptr_array(grads[3::4]), ws.data_ptr(), nbytes, _stream(dev))

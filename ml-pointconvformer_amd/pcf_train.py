@@ -82,6 +82,28 @@ def build_edges(cfg, pointclouds, points_stored):
     return es, ef, ep, inv
 
 
+def make_optimizer(cfg, model):
+    """AdamW as the training script builds it (train_ScanNet_DDP_WarmUP.py:237-241), as ONE multi-tensor kernel per
+    step on the GPU (`fused=True`): the default for-each form issues ~115 launches over the 196 parameter tensors and
+    costs 5 ms of host time per iteration -- more than the GPU spends on the optimizer."""
+    params = list(model.parameters())
+    fused = all(p.is_cuda for p in params)
+    return torch.optim.AdamW(params, lr=cfg.learning_rate, weight_decay=cfg.adamw_decay, fused=fused)
+
+
+@torch.no_grad()
+def clip_grad_norm_(optimizer, max_norm):
+    """torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm) (train_ScanNet_DDP_WarmUP.py:421) over the
+    optimizer's own parameter lists: same arithmetic (2-norm of the per-tensor 2-norms, coefficient clamped to 1,
+    gradients scaled in place), without walking the module tree of ~850 modules every iteration."""
+    grads = [p.grad for g in optimizer.param_groups for p in g['params'] if p.grad is not None]
+    if not grads:
+        return torch.zeros(())
+    total = torch.linalg.vector_norm(torch.stack(torch._foreach_norm(grads)))
+    torch._foreach_mul_(grads, torch.clamp(max_norm / (total + 1e-6), max=1.0))
+    return total
+
+
 def training_iteration(model, optimizer, criterion, cfg, batch, edges=None):
     """One optimisation step on one packed batch; returns the loss tensor (no host sync)."""
     features, pointclouds, target, norms, points_stored = batch
@@ -89,7 +111,7 @@ def training_iteration(model, optimizer, criterion, cfg, batch, edges=None):
     pred = model(features, pointclouds, es, ef, ep, norms, *inv)
     loss = criterion(pred.reshape(-1, cfg.num_classes), target)
     loss.backward()
-    torch.nn.utils.clip_grad_norm_(model.parameters(), 10)
+    clip_grad_norm_(optimizer, 10)
     optimizer.step()
     optimizer.zero_grad(set_to_none=True)
     return loss.detach()

@@ -95,9 +95,10 @@ def test_pconv_forward_backward(device, shape):
     torch.testing.assert_close(gx.cpu(), wx, **TOL)
 
 
-def test_out_of_range_neighbours_are_ignored(device):
+@pytest.mark.parametrize('Cm', [16, 1])
+def test_out_of_range_neighbours_are_ignored(device, Cm):
     import pcf_cuda
-    B, N, Nout, K, Ci, Ca, Cm, H = 1, 120, 80, 16, 16, 4, 16, 8
+    B, N, Nout, K, Ci, Ca, H = 1, 120, 80, 16, 16, 4, 8
     x, idx, guid, w, add = _case(B, N, Nout, K, Ci, Ca, Cm, H, seed=5, bad_frac=0.2)
     sidx, ok = _safe(idx, N)
     d = lambda t: t.to(device)
@@ -179,6 +180,9 @@ LIN_SHAPES = [
     (2, 90, 90, 8, 8, 4, 4, 16),
     (1, 1000, 1000, 16, 3, 0, 16, 32),    # enough points for a split-K reduction of grad_lin_w
     (1, 64, 64, 16, 3, 0, 1, 5),          # J = 3: scalar GEMM loads
+    (2, 70, 110, 5, 192, 32, 1, 24),      # C_mid = 1 kernels: batch 2, odd K, 48 quads per row (not a power of two)
+    (1, 50, 120, 16, 384, 32, 1, 40),     # C_mid = 1, widest decoder layer: two lane passes per row
+    (1, 90, 60, 16, 8, 0, 1, 12),         # C_mid = 1, two quads per row: 32 list entries per wave step
 ]
 
 
