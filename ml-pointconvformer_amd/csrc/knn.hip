@@ -145,15 +145,20 @@ __global__ __launch_bounds__(BLOCK) void scan_chunk_offsets_kernel(int32_t* __re
     }
 }
 
-// phase c: inv_idx[i] = exclusive prefix of counts; inv_idx[n] = grand total
-__global__ __launch_bounds__(BLOCK) void scan_write_kernel(const int32_t* __restrict__ counts,
+// phase c: inv_idx[i] = exclusive prefix of counts; inv_idx[n] = grand total.  `clear` leaves counts zeroed for its
+// second life as the per-bucket cursor of the fill pass (saves a memset launch per call).
+__global__ __launch_bounds__(BLOCK) void scan_write_kernel(int32_t* __restrict__ counts,
                                                            const int32_t* __restrict__ chunk_offsets,
-                                                           int32_t* __restrict__ inv_idx, int n) {
+                                                           int32_t* __restrict__ inv_idx, int n, bool clear) {
     const int base = blockIdx.x * SCAN_CHUNK + threadIdx.x * 4;
     int c[4];
     int v = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { c[i] = (base + i < n) ? counts[base + i] : 0; v += c[i]; }
+    for (int i = 0; i < 4; ++i) {
+        c[i] = (base + i < n) ? counts[base + i] : 0;
+        v += c[i];
+        if (clear && base + i < n) counts[base + i] = 0;
+    }
     int total;
     int run = chunk_offsets[blockIdx.x] + block_exclusive_scan(v, &total);
 #pragma unroll
@@ -165,7 +170,7 @@ __global__ __launch_bounds__(BLOCK) void scan_write_kernel(const int32_t* __rest
 }
 
 // out[i] = sum of counts[0..i) for i in [0, n]; chunk_tmp holds ceil(n / 1024) ints.  (also used by knn_grid.hip)
-int exclusive_scan_i32(const int32_t* counts, int32_t* chunk_tmp, int32_t* out, int n, hipStream_t s) {
+int exclusive_scan_i32(int32_t* counts, int32_t* chunk_tmp, int32_t* out, int n, bool clear_counts, hipStream_t s) {
     if (n <= 0) {
         hipError_t e = hipMemsetAsync(out, 0, 4, s);
         return e == hipSuccess ? ok() : fail(PCF_E_LAUNCH, "scan: %s", hipGetErrorString(e));
@@ -173,7 +178,7 @@ int exclusive_scan_i32(const int32_t* counts, int32_t* chunk_tmp, int32_t* out, 
     const int nchunks = ceil_div(n, SCAN_CHUNK);
     hipLaunchKernelGGL(scan_chunk_sums_kernel, dim3(nchunks), dim3(BLOCK), 0, s, counts, chunk_tmp, n);
     hipLaunchKernelGGL(scan_chunk_offsets_kernel, dim3(1), dim3(BLOCK), 0, s, chunk_tmp, nchunks);
-    hipLaunchKernelGGL(scan_write_kernel, dim3(nchunks), dim3(BLOCK), 0, s, counts, chunk_tmp, out, n);
+    hipLaunchKernelGGL(scan_write_kernel, dim3(nchunks), dim3(BLOCK), 0, s, counts, chunk_tmp, out, n, clear_counts);
     return check_launch("exclusive scan");
 }
 
@@ -202,8 +207,14 @@ __global__ __launch_bounds__(BLOCK) void csr_sort_small_kernel(const uint32_t* _
                                                                const int32_t* __restrict__ inv_idx, int total_points,
                                                                int K, int32_t* __restrict__ inv_n,
                                                                uint8_t* __restrict__ inv_k, int32_t* __restrict__ big_list,
-                                                               int32_t* __restrict__ big_count) {
+                                                               int32_t* __restrict__ big_count, long long edges) {
     const int lane = lane_id();
+    // slots past the last valid edge (out-of-range neighbour indices leave some) read as zero
+    for (long long e = inv_idx[total_points] + (long long)blockIdx.x * BLOCK + threadIdx.x; e < edges;
+         e += (long long)gridDim.x * BLOCK) {
+        inv_n[e] = 0;
+        inv_k[e] = 0;
+    }
     for (int t = blockIdx.x * NWAVE + wave_id(); t < total_points; t += gridDim.x * NWAVE) {
         const int beg = inv_idx[t], end = inv_idx[t + 1];
         const int d = end - beg;
@@ -280,11 +291,11 @@ static CsrWs csr_plan(int Nq, int K, int total_points) {
     CsrWs w{};
     w.nchunks = std::max(1, ceil_div(total_points, SCAN_CHUNK));
     size_t off = 0;
-    w.off_counts = off;   off = align_up(off + (size_t)std::max(total_points, 1) * 4, 256);
+    w.off_counts = off;   off = align_up(off + (size_t)(std::max(total_points, 1) + 1) * 4, 256);   // + the big-bucket count
     w.off_chunks = off;   off = align_up(off + (size_t)w.nchunks * 4, 256);
     w.off_keys = off;     off = align_up(off + (size_t)Nq * K * 4 + 4, 256);
     w.off_big = off;      off = align_up(off + (size_t)std::max(total_points, 1) * 4, 256);
-    w.off_bigcount = off; off = align_up(off + 4, 256);
+    w.off_bigcount = w.off_counts + (size_t)std::max(total_points, 1) * 4;      // cleared with the counts in one memset
     w.bytes = off;
     return w;
 }
@@ -345,30 +356,28 @@ int pcf_hip_knn_inverse(const int64_t* idx, int32_t* inv_neighbors, uint8_t* inv
         int32_t* nb = inv_neighbors + (size_t)b * edges;
         uint8_t* kb = inv_k + (size_t)b * edges;
         int32_t* xb = inv_idx + (size_t)b * (total_points + 1);
-        if (edges) {
-            PCF_HIP(hipMemsetAsync(nb, 0, (size_t)edges * 4, s));
-            PCF_HIP(hipMemsetAsync(kb, 0, (size_t)edges, s));
-        }
         if (total_points == 0) {
+            if (edges) {
+                PCF_HIP(hipMemsetAsync(nb, 0, (size_t)edges * 4, s));
+                PCF_HIP(hipMemsetAsync(kb, 0, (size_t)edges, s));
+            }
             PCF_HIP(hipMemsetAsync(xb, 0, 4, s));
             continue;
         }
-        PCF_HIP(hipMemsetAsync(counts, 0, (size_t)total_points * 4, s));
-        PCF_HIP(hipMemsetAsync(bigc, 0, 4, s));
+        PCF_HIP(hipMemsetAsync(counts, 0, (size_t)(total_points + 1) * 4, s));       // histogram + big-bucket count
         if (edges) {
             hipLaunchKernelGGL(csr_count_kernel, dim3(egrid), dim3(BLOCK), 0, s, ib, counts, edges, total_points);
             if (int e = check_launch("knn_inverse histogram")) return e;
         }
         hipLaunchKernelGGL(scan_chunk_sums_kernel, dim3(w.nchunks), dim3(BLOCK), 0, s, counts, chunks, total_points);
         hipLaunchKernelGGL(scan_chunk_offsets_kernel, dim3(1), dim3(BLOCK), 0, s, chunks, w.nchunks);
-        hipLaunchKernelGGL(scan_write_kernel, dim3(w.nchunks), dim3(BLOCK), 0, s, counts, chunks, xb, total_points);
+        hipLaunchKernelGGL(scan_write_kernel, dim3(w.nchunks), dim3(BLOCK), 0, s, counts, chunks, xb, total_points, true);
         if (int e = check_launch("knn_inverse scan")) return e;
         if (edges) {
-            PCF_HIP(hipMemsetAsync(counts, 0, (size_t)total_points * 4, s));
             hipLaunchKernelGGL(csr_fill_kernel, dim3(egrid), dim3(BLOCK), 0, s, ib, xb, counts, keys, edges, total_points);
             const int sgrid = std::max(1, std::min(ceil_div(total_points, NWAVE), 8192));
             hipLaunchKernelGGL(csr_sort_small_kernel, dim3(sgrid), dim3(BLOCK), 0, s, keys, xb, total_points, K, nb, kb,
-                               big, bigc);
+                               big, bigc, edges);
             hipLaunchKernelGGL(csr_sort_large_kernel, dim3(1024), dim3(BLOCK), 0, s, keys, xb, K, nb, kb, big, bigc);
             if (int e = check_launch("knn_inverse fill/sort")) return e;
         }

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(BLOCK) void knn_grid_kernel(const float* __restrict
         if (s < K) out[(size_t)q * K + s] = best[s] == ~0ull ? -1ll : (long long)(unsigned int)(best[s] & 0xffffffffull);
 }
 
-int exclusive_scan_i32(const int32_t* counts, int32_t* chunk_tmp, int32_t* out, int n, hipStream_t s);   // knn.hip
+int exclusive_scan_i32(int32_t* counts, int32_t* chunk_tmp, int32_t* out, int n, bool clear_counts, hipStream_t s);   // knn.hip
 
 struct GridWs {
     size_t off_grids, off_cellpt, off_counts, off_start, off_chunks, off_sorted, bytes;
@@ -261,8 +261,7 @@ int pcf_hip_knn_grid(const float* ref, const float* query, const int32_t* ref_of
     const int pgrid = std::max(1, std::min(ceil_div(std::max(n_ref, 1), BLOCK), 2048));
     hipLaunchKernelGGL(cell_count_kernel, dim3(pgrid), dim3(BLOCK), 0, s, ref, ref_off, n_seg, n_ref, grids, cellpt, counts);
     if (int e = check_launch("knn_grid: cell histogram")) return e;
-    if (int e = exclusive_scan_i32(counts, chunks, start, w.n_cells, s)) return e;
-    PCF_HIP(hipMemsetAsync(counts, 0, (size_t)(w.n_cells + 1) * 4, s));
+    if (int e = exclusive_scan_i32(counts, chunks, start, w.n_cells, true, s)) return e;      // leaves counts zeroed
     hipLaunchKernelGGL(cell_fill_kernel, dim3(pgrid), dim3(BLOCK), 0, s, ref, n_ref, cellpt, start, counts, sorted);
     const dim3 qgrid(ceil_div(n_query, BLOCK));
     if (K <= 8) hipLaunchKernelGGL(knn_grid_kernel<8>, qgrid, dim3(BLOCK), 0, s, query, query_off, n_seg, n_query, grids, start, sorted, K, out);

@@ -159,4 +159,4 @@ class PointConvFormer_Segmentation(pcf_fused.CounterScope):
                 vi = vi_new if vi is None else vi
             feats[lvl] = x
         x = self.dropout_fc(_linear_act(self.fc1, x, pcf_fused.ACT_RELU))
-        return self.fc2(x)
+        return _linear_act(self.fc2, x, pcf_fused.ACT_NONE)       # the classifier on the same contraction kernels
