@@ -131,7 +131,7 @@ def bench_train(args):
     for b in range(2):
         scenes = [pcf_train.synthetic_scene(args.points, cfg.grid_size, seed=1000 * (rank + 1) + 10 * b + i, device=dev)
                   for i in range(args.scenes)]
-        pool.append(pcf_train.pack_batch(scenes))
+        pool.append(pcf_train.pack_batch(scenes, cfg.grid_size))
     n_pts = sum(pool[0][4][0])
 
     def step(i):
@@ -159,13 +159,105 @@ def bench_train(args):
     pcf_dist.shutdown()
 
 
+def bench_subsample(args):
+    """Tertiary workload: the multi-resolution levels of one packed batch -- levels 1..4 of
+    `--scenes` scenes x `--points` level-0 points by barycentre grid subsampling with the configPCF_10cm_lite grid
+    sizes (datasetCommon.subsample, :384-421) -- on the GPU; a step = one knn_post_dataloader_utils.subsample_packed
+    call (four pcf_hip_grid_subsample launches + the per-level count read-back).  cpu_baseline = the reference's own
+    C++ (oracle/_ref, kind "reference") run per scene on one host core, as its dataloader workers do."""
+    import pcf_dist
+    rank, world, local_rank, dev = pcf_dist.setup('nccl')
+    import knn_post_dataloader_utils as U
+    import pcf_cuda
+    import pcf_train
+    grid = LITE_YAML['grid_size']
+    scenes = [pcf_train.synthetic_scene(args.points, grid, seed=1000 * (rank + 1) + i, device=dev) for i in range(args.scenes)]
+    xyz = torch.cat([s['xyz'] for s in scenes])
+    nrm = torch.cat([s['nrm'] for s in scenes])
+    counts = [int(s['xyz'].shape[0]) for s in scenes]
+    n0 = sum(counts)
+
+    def step():
+        return U.subsample_packed(xyz, nrm, counts, grid)
+
+    for _ in range(args.warmup):
+        step()
+    timeline = pcf_cuda.record_kernel_times(True, only=('pcf_hip_grid_subsample',))
+    pcf_dist.fence(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pcs, _, stored = step()
+    pcf_dist.fence(dev)
+    elapsed = pcf_dist.max_over_ranks(time.perf_counter() - t0, dev)
+    pcf_cuda.record_kernel_times(False)
+    if rank != 0:
+        pcf_dist.shutdown()
+        return
+    level_in = [sum(c) for c in stored[:-1]]          # points entering each of the four launches
+    level_out = [sum(c) for c in stored[1:]]
+    # algorithmic bytes of one launch: box 12 + key 12 read, (key 8 + index 4) written; 8 radix passes x (12 read +
+    # 12 written); run heads 8 + 4, scan 3 x 4; gather of point + normal rows 24; 24 written per voxel
+    alg = [n * (12 + 12 + 12 + 8 * 24 + 12 + 12 + 24) + m * 24 for n, m in zip(level_in, level_out)]
+    dev_ms = [e0.elapsed_time(e1) for _, e0, e1 in timeline]
+    per_step_ms = sum(dev_ms) / args.steps
+    achieved = sum(alg) / (per_step_ms * 1e-3) / 1e9
+    line = {
+        'metric': 'multi-level grid subsampling, level-0 points/sec (4 scenes x 40k, 4 levels)',
+        'value': round(world * n0 * args.steps / elapsed, 1), 'unit': 'points/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 sums / u64 keys', 'data': 'synthetic',
+        'config': {'workload': f'{args.scenes} scenes x ~{args.points} level-0 points per GPU ({n0} points), grid sizes '
+                               f'{grid}, levels {[sum(c) for c in stored]}', 'parallelism': f'dp{world}'},
+        'roofline': {'bound': 'hbm', 'kernel': 'pcf_hip_grid_subsample (keys, rocPRIM radix sort, run heads, means)',
+                     'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': None,
+                     'algorithmic_bytes_per_launch': int(sum(alg) / len(alg)),
+                     'avg_launch_ms': round(per_step_ms / len(alg), 4)}}
+    if not args.no_cpu_baseline:
+        line['cpu_baseline'] = cpu_baseline_subsample([s['xyz'].cpu().numpy() for s in scenes],
+                                                      [s['nrm'].cpu().numpy() for s in scenes], grid, n0)
+    print(json.dumps(line), flush=True)
+    pcf_dist.shutdown()
+
+
+def cpu_baseline_subsample(xyzs, nrms, grid, n0, iters=5):
+    """The same batch through the reference's C++ (oracle/_ref; "reference") or, where that file did not travel, the
+    oracle's numpy restatement ("port"): scene by scene, level by level, one core."""
+    from oracle import grid_subsample_oracle as G
+    from oracle import gridsub_ref as R
+    kind = 'reference' if R.available() else 'port'
+    fn = R.grid_subsampling if kind == 'reference' else (lambda p, f, l, dl: G.grid_subsampling(p, f, l, dl))
+
+    def run():
+        for p, f in zip(xyzs, nrms):
+            for gs in grid[1:]:
+                q, g, _ = fn(p, f, None, gs)
+                if q.shape[0] > 16:
+                    if kind == 'reference':            # hand the next level the canonical row order, as the GPU does
+                        o = G.lex_order(q)
+                        q, g = q[o], g[o]
+                    p, f = q, g
+    run()
+    ts = []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        run()
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    med = ts[len(ts) // 2]
+    return {'value': round(n0 / med, 1), 'unit': 'points/s', 'cores': 1, 'kind': kind,
+            'sample': f'full workload ({len(xyzs)} scenes, {n0} level-0 points, 4 levels), 1 warm-up + {iters} timed runs, '
+                      f'median {med * 1e3:.1f} ms; grid_subsampling.cpp:9-110 compiled from the reference sources'
+                      if kind == 'reference' else f'full workload, numpy restatement, median {med * 1e3:.1f} ms'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--points', type=int, default=None)
-    ap.add_argument('--workload', choices=['layer', 'train'], default='layer')
+    ap.add_argument('--workload', choices=['layer', 'train', 'subsample'], default='layer')
     ap.add_argument('--scenes', type=int, default=4, help='scenes per GPU per iteration (train workload)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true',
@@ -182,6 +274,8 @@ def main():
         args.points = N_POINTS if args.workload == 'layer' else 40000
     if args.workload == 'train':
         return bench_train(args)
+    if args.workload == 'subsample':
+        return bench_subsample(args)
 
     import pcf_dist
     rank, world, local_rank = pcf_dist.env_rank()

@@ -148,6 +148,24 @@ int pcf_hip_knn_grid(const float* ref, const float* query, const int32_t* ref_of
                      int n_seg, int n_ref, int n_query, int K, int64_t* out, void* workspace,
                      size_t workspace_bytes, void* stream);
 
+/* ---- multi-resolution levels: barycentre grid subsampling of a packed batch --------------------------
+ * replaces cpp_subsampling.compute(points, features=..., sampleDl=..., method="barycenters")
+ *   (cpp_wrappers/cpp_subsampling/wrapper.cpp:200-290 -> grid_subsampling/grid_subsampling.cpp:9-110),
+ * as called per sample and level from datasetCommon.grid_subsampling / subsample (datasetCommon.py:17-67, :384-421).
+ * points [N,3] f32 and features [N,F] f32 (F may be 0: features NULL) packed over n_seg samples; seg_off i32
+ * [n_seg+1] (device) are the per-sample prefix offsets.  Per sample: origin = floor(min_corner * (1/dl)) * dl and
+ * voxel (i,j,k) = floor((p - origin) / dl) in fp32 as the reference computes them; every occupied voxel yields the
+ * barycentre of its points (float sum in point order x float(1.0/count)) and the mean of their features (float sum
+ * / float(count)) -- bit-identical to the reference.  Output order: by sample, then by the reference's linear voxel
+ * index i + nX*j + nX*nY*k ascending (the reference itself emits std::unordered_map order).
+ * out_points [N,3] / out_features [N,F] have room for N rows; out_seg_counts i32 [n_seg] receives the voxels per
+ * sample and out_total i32 [2] = {voxel total, status} (status != 0: a sample spans >= 2^18 voxels along an axis or
+ * holds non-finite coordinates).  All on `stream`; nothing is read back by the library. */
+size_t pcf_hip_grid_subsample_workspace_bytes(int n_points, int n_seg);
+int pcf_hip_grid_subsample(const float* points, const float* features, const int32_t* seg_off, int n_seg, int n_points,
+                           int F, float sampleDl, float* out_points, float* out_features, int32_t* out_seg_counts,
+                           int32_t* out_total, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- per-edge helpers around the aggregate ---------------------------------------------------
  * replace index_points (layer_utils.py:13-30) and its index_put_ backward: */
 /* out[b,s,:] = table[b, idx[b,s], :]   table [B,N,C], idx [B,S] i64 (S = M*K for a neighbour table) */

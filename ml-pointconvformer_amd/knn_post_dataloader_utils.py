@@ -25,7 +25,7 @@ import torch
 import pcf_cuda
 
 __all__ = ['compute_knn', 'compute_knn_packed', 'prepare', 'listToBatch', 'tensorize', 'tensorizeTensorList',
-           'compute_knn_inverse']
+           'compute_knn_inverse', 'subsample_packed']
 
 
 def _device():
@@ -178,3 +178,37 @@ def compute_knn_inverse(pointclouds, edges_self, edges_forward, edges_propagate)
                 dst.append(t)
         return list(out)
     return build(edges_self), build(edges_forward), build(edges_propagate)
+
+
+def subsample_packed(coord, norm, points_stored0, grid_size, min_points=16):
+    """The multi-resolution levels of a packed batch, on the GPU: ``datasetCommon.subsample`` (:384-421) for every
+    sample of the batch at once.  coord / norm: [N,3] (or [1,N,3]) packed level-0 coordinates and unit normals,
+    points_stored0: points per sample.  Level 0 is the input; level j is the barycentre grid subsampling of level
+    j-1 at grid_size[j] with the normals averaged per voxel (not re-normalised, as upstream); a sample whose level
+    would have <= ``min_points`` points repeats its previous level (:413-414).
+
+    Returns (pointclouds, norms, points_stored) in the collate layout: lists over levels of [1, sum_i N_i, 3] tensors
+    and per-level lists of per-sample counts -- what ``compute_knn_packed`` takes next."""
+    p = _as_device_points(coord)
+    f = _as_device_points(norm)
+    counts = [int(c) for c in points_stored0]
+    if sum(counts) != p.shape[0] or f.shape[0] != p.shape[0]:
+        raise RuntimeError('subsample_packed: points_stored0 must sum to the number of points and normals')
+    pointclouds, norms, stored = [p], [f], [counts]
+    for gs in list(grid_size)[1:]:
+        prev_p, prev_f, prev_c = pointclouds[-1], norms[-1], stored[-1]
+        _, off = _offsets(prev_c, prev_p.device)
+        sp, sf, sc = pcf_cuda.grid_subsample(prev_p, prev_f, off, float(gs))
+        if any(c <= min_points for c in sc):           # rare: keep the previous level for those samples only
+            parts_p, parts_f, a, b = [], [], 0, 0
+            for c_new, c_old in zip(sc, prev_c):
+                keep_old = c_new <= min_points
+                parts_p.append(prev_p[b:b + c_old] if keep_old else sp[a:a + c_new])
+                parts_f.append(prev_f[b:b + c_old] if keep_old else sf[a:a + c_new])
+                a, b = a + c_new, b + c_old
+            sp, sf = torch.cat(parts_p), torch.cat(parts_f)
+            sc = [c_old if c_new <= min_points else c_new for c_new, c_old in zip(sc, prev_c)]
+        pointclouds.append(sp.contiguous())
+        norms.append(sf.contiguous())
+        stored.append(list(sc))
+    return [t[None] for t in pointclouds], [t[None] for t in norms], stored

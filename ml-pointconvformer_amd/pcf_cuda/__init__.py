@@ -72,6 +72,8 @@ _inv_ws = _sig('pcf_hip_knn_inverse_workspace_bytes', [_I] * 4, _Z)
 _inv = _sig('pcf_hip_knn_inverse', [_P] * 5 + [_Z] + [_I] * 4 + [_P])
 _knn = _sig('pcf_hip_knn', [_P] * 4 + [_I] * 3 + [_P] * 2)
 _knn_grid_ws = _sig('pcf_hip_knn_grid_workspace_bytes', [_I, _I], _Z)
+_gridsub_ws = _sig('pcf_hip_grid_subsample_workspace_bytes', [_I, _I], _Z)
+_gridsub = _sig('pcf_hip_grid_subsample', [_P, _P, _P, _I, _I, _I, ctypes.c_float, _P, _P, _P, _P, _P, _Z, _P])
 _knn_grid = _sig('pcf_hip_knn_grid', [_P] * 4 + [_I] * 4 + [_P, _P, _Z, _P])
 _gemm_nt = _sig('pcf_hip_gemm_nt', [_P] * 4 + [_I] * 3 + [_P])
 
@@ -429,6 +431,51 @@ def knn_packed(ref, query, ref_offsets, query_offsets, K, method='auto'):
             _call(_knn, _ptr(ref), _ptr(query), ref_offsets.data_ptr(), query_offsets.data_ptr(), S, n_query, int(K),
                   _ptr(out), _stream(dev))
     return out
+
+
+def grid_subsample(points, features=None, offsets=None, sampleDl=0.1):
+    """Barycentre grid subsampling of a packed batch (GPU form of ``cpp_subsampling.compute(points, features=...,
+    sampleDl=..., method="barycenters")``, datasetCommon.py:17-67, applied to every sample of the batch in one call).
+
+    points [N,3] f32 and optional features [N,F] f32 device tensors packed over S samples; offsets int32 [S+1]
+    device tensor of per-sample prefix offsets (None: one sample).  Returns (sub_points [M,3], sub_features [M,F] or
+    None, counts) with ``counts`` a host list of the voxels per sample: voxels are ordered by sample, then by the
+    reference's linear voxel index; barycentres and feature means are bit-identical to the reference's.  Reading
+    ``counts`` is the one device->host sync (the output size is data dependent, as with torch.unique)."""
+    _floats(points=points)
+    if points.dim() != 2 or points.shape[1] != 3:
+        raise RuntimeError('pcf_cuda: points must be [n,3]')
+    n = points.shape[0]
+    F = 0
+    if features is not None:
+        _floats(features=features)
+        if features.dim() != 2 or features.shape[0] != n:
+            raise RuntimeError('pcf_cuda: features must be [n,F] with one row per point')
+        F = features.shape[1]
+    dev = points.device
+    if offsets is None:
+        offsets = torch.tensor([0, n], dtype=torch.int32, device=dev)
+    _check_input(offsets, 'offsets', torch.int32)
+    S = offsets.numel() - 1
+    if S < 0:
+        raise RuntimeError('pcf_cuda: offsets must be [num_samples+1]')
+    if not sampleDl > 0:
+        raise ValueError('grid_subsample: sampleDl must be positive')
+    out_p = torch.empty(n, 3, dtype=torch.float32, device=dev)
+    out_f = torch.empty(n, F, dtype=torch.float32, device=dev) if F else None
+    meta = torch.empty(S + 2, dtype=torch.int32, device=dev)          # [total, status, counts...]
+    with _guard(dev):
+        nbytes = _gridsub_ws(n, S)
+        ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=dev)
+        _call(_gridsub, _ptr(points), _ptr(features) if F else None, offsets.data_ptr(), S, n, F, float(sampleDl),
+              _ptr(out_p), _ptr(out_f) if F else None, meta.data_ptr() + 8, meta.data_ptr(), ws.data_ptr(), nbytes,
+              _stream(dev))
+    host = meta.cpu().tolist()
+    total, status, counts = host[0], host[1], host[2:]
+    if status != 0:
+        raise RuntimeError('pcf_cuda: grid_subsample: a sample spans 2^18 or more voxels along an axis (or holds '
+                           'non-finite coordinates) at sampleDl=%g' % sampleDl)
+    return out_p[:total], (out_f[:total] if F else None), counts
 
 
 def gemm_nt(a, b, bias=None):

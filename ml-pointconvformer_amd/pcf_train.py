@@ -9,9 +9,10 @@ sequence of device work per iteration (``train_ScanNet_DDP_WarmUP.py:376-424``):
     forward, cross-entropy, backward, clip_grad_norm_(10), optimizer step   :404-424
 
 Scenes are points on a gently folded surface (indoor scans are 2-D manifolds: each halving of the
-resolution keeps about a quarter of the points), voxel-grid subsampled on the GPU once per level with
-the YAML's ``grid_size`` ratios, packed over the batch exactly like ``datasetCommon.py:348-379``
-([1, sum_i N_i, C] tensors + per-sample counts).
+resolution keeps about a quarter of the points), thinned to the level-0 resolution, packed over the batch
+exactly like ``datasetCommon.py:348-379`` ([1, sum_i N_i, C] tensors + per-sample counts) and subsampled
+level by level with the YAML's ``grid_size`` ratios by the HIP barycentre grid subsampling
+(``datasetCommon.subsample`` :384-421 on the GPU).
 """
 from __future__ import annotations
 
@@ -22,8 +23,9 @@ import torch
 import knn_post_dataloader_utils as knn_utils
 
 
-def _grid_subsample(xyz, grid):
-    """One point per occupied voxel of edge `grid` (the first in index order) -> indices, ascending."""
+def _voxelize_first(xyz, grid):
+    """One point per occupied voxel of edge `grid` (the first in index order) -> indices, ascending: the deterministic
+    mode of util/voxelize.py:44-82, which thins the raw scan to the level-0 resolution."""
     v = torch.floor(xyz / grid).to(torch.int64)
     v = v - v.min(0, keepdim=True)[0]
     dims = v.max(0)[0] + 1
@@ -36,8 +38,8 @@ def _grid_subsample(xyz, grid):
 
 
 def synthetic_scene(n_points, grid_sizes, seed, device, n_features=3, n_classes=20):
-    """One scene: per-level xyz / unit normals, level-0 features and labels.  The level-0 cloud has about
-    `n_points` points after voxelisation at grid_sizes[0]."""
+    """One scene at the level-0 resolution: xyz, unit normals, features and labels of about `n_points` points after
+    voxelisation at grid_sizes[0].  The coarser levels are made per batch by `pack_batch`."""
     g = torch.Generator().manual_seed(seed)
     side = grid_sizes[0] * math.sqrt(n_points) * 1.05           # ~1 point per level-0 voxel of the sheet
     m = int(n_points * 1.6)
@@ -48,27 +50,24 @@ def synthetic_scene(n_points, grid_sizes, seed, device, n_features=3, n_classes=
     dzdx = 0.35 * fx * torch.cos(fx * xy[:, 0])
     dzdy = -0.25 * fy * torch.sin(fy * xy[:, 1])
     nrm = torch.nn.functional.normalize(torch.stack([-dzdx, -dzdy, torch.ones_like(dzdx)], 1), dim=1).to(device)
-    keep = _grid_subsample(xyz, grid_sizes[0])[:n_points]
-    levels_xyz, levels_nrm = [xyz[keep]], [nrm[keep]]
-    for gs in grid_sizes[1:]:
-        sel = _grid_subsample(levels_xyz[-1], gs)
-        levels_xyz.append(levels_xyz[-1][sel])
-        levels_nrm.append(levels_nrm[-1][sel])
-    n0 = levels_xyz[0].shape[0]
+    keep = _voxelize_first(xyz, grid_sizes[0])[:n_points]
+    n0 = keep.shape[0]
     feats = torch.randn(n0, n_features, generator=g).to(device)
     labels = torch.randint(0, n_classes, (n0,), generator=g).to(device)
-    return dict(xyz=levels_xyz, nrm=levels_nrm, features=feats, labels=labels)
+    return dict(xyz=xyz[keep].contiguous(), nrm=nrm[keep].contiguous(), features=feats, labels=labels)
 
 
-def pack_batch(scenes):
-    """Scenes -> the packed batch the collate function emits: features [1,sumN0,C], pointclouds /
-    norms lists of [1,sumN_l,3], target [sumN0], points_stored [level][sample]."""
-    L = len(scenes[0]['xyz'])
-    pointclouds = [torch.cat([s['xyz'][l] for s in scenes])[None].contiguous() for l in range(L)]
-    norms = [torch.cat([s['nrm'][l] for s in scenes])[None].contiguous() for l in range(L)]
+def pack_batch(scenes, grid_sizes):
+    """Scenes -> the packed batch the collate function emits (datasetCommon.py:348-379): features [1,sumN0,C],
+    pointclouds / norms lists of [1,sumN_l,3], target [sumN0], points_stored [level][sample].  The levels are the
+    barycentre grid subsampling of the reference's dataloader (datasetCommon.subsample, :384-421), run on the GPU over
+    the whole packed batch (knn_post_dataloader_utils.subsample_packed -> pcf_hip_grid_subsample)."""
+    xyz = torch.cat([s['xyz'] for s in scenes])
+    nrm = torch.cat([s['nrm'] for s in scenes])
+    pointclouds, norms, points_stored = knn_utils.subsample_packed(xyz, nrm, [int(s['xyz'].shape[0]) for s in scenes],
+                                                                   grid_sizes)
     features = torch.cat([s['features'] for s in scenes])[None].contiguous()
     target = torch.cat([s['labels'] for s in scenes])
-    points_stored = [[int(s['xyz'][l].shape[0]) for s in scenes] for l in range(L)]
     return features, pointclouds, target, norms, points_stored
 
 
