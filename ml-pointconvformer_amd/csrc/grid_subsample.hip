@@ -116,15 +116,28 @@ __global__ __launch_bounds__(BLOCK) void run_start_kernel(const unsigned long lo
                                                           const int32_t* __restrict__ vid, int n,
                                                           int32_t* __restrict__ start, int32_t* __restrict__ seg_counts,
                                                           int32_t* __restrict__ total) {
-    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
-        const bool head = (i == 0) || keys[i] != keys[i - 1];
-        if (head) {
-            start[vid[i]] = i;
-            atomicAdd(&seg_counts[(int)(keys[i] >> (3 * AXIS_BITS))], 1);
+    const int lane = lane_id();
+    for (int i0 = blockIdx.x * BLOCK; i0 < n; i0 += gridDim.x * BLOCK) {       // whole waves stay in the loop (ballots)
+        const int i = i0 + threadIdx.x;
+        bool head = false;
+        int seg = -1;
+        if (i < n) {
+            head = (i == 0) || keys[i] != keys[i - 1];
+            seg = (int)(keys[i] >> (3 * AXIS_BITS));
+            if (head) start[vid[i]] = i;
+            if (i == n - 1) {
+                start[vid[n]] = n;
+                *total = vid[n];
+            }
         }
-        if (i == n - 1) {
-            start[vid[n]] = n;
-            *total = vid[n];
+        // voxels per sample: one atomic per (wave, sample) -- 50k heads on four counters serialise otherwise (205 us)
+        unsigned long long todo = __ballot(head);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int s0 = __shfl(seg, leader, WAVE);
+            const unsigned long long m = __ballot(head && seg == s0);
+            if (lane == leader) atomicAdd(&seg_counts[s0], (int)__popcll(m));
+            todo &= ~m;
         }
     }
 }
