@@ -141,6 +141,12 @@ int pcf_hip_knn_inverse(const int64_t* idx, int32_t* inv_neighbors, uint8_t* inv
 int pcf_hip_knn(const float* ref, const float* query, const int32_t* ref_off, const int32_t* query_off,
                 int n_seg, int max_queries_per_seg, int K, int64_t* out, void* stream);
 
+/* Same contract and bit-identical output as pcf_hip_knn, one wave per query (64 lanes share the distance evaluations
+ * and select the K smallest by wave-wide minimum rounds): the engine for the coarse levels, where a few thousand
+ * queries leave lane-per-query kernels latency-bound.  Cost ~ n_query x ceil(refs per sample / 1024). */
+int pcf_hip_knn_wave(const float* ref, const float* query, const int32_t* ref_off, const int32_t* query_off,
+                     int n_seg, int n_query, int K, int64_t* out, void* stream);
+
 /* Same contract and bit-identical output as pcf_hip_knn, through a uniform-grid index over the reference
  * points (cell sort + ring search); the engine for large clouds.  n_ref / n_query are the packed totals. */
 size_t pcf_hip_knn_grid_workspace_bytes(int n_ref, int n_seg);

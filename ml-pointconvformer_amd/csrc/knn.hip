@@ -78,6 +78,90 @@ __global__ __launch_bounds__(BLOCK) void knn_kernel(const float* __restrict__ re
     }
 }
 
+
+// ---- one wave per query: the coarse levels -------------------------------------------------------------------
+// With a few thousand queries the lane-per-query kernels above and in knn_grid.hip are pure latency (a level of
+// 1.3k points takes 100-220 us: six workgroups walking their candidates one by one).  Here the 64 lanes of a wave
+// share one query: its sample's references are taken 64 x WPER at a time, every lane holds WPER candidate keys
+// (distance bits << 32 | packed index: unsigned order == the oracle's (distance, index) order) plus one slot for a
+// carried best, and K rounds of {lane minimum, xor-butterfly minimum over the wave, winner drops its key} extract the
+// K smallest; the K best so far ride along in lanes 0..K-1 from chunk to chunk.  Same distance expression and
+// roundings as knn_kernel, so the lists are bit-identical.  Cost ~ queries x ceil(refs per sample / 1024).
+constexpr int WPER = 16;
+constexpr unsigned long long KEY_NONE = ~0ull;
+
+// minimum over the 64 lanes, returned to all of them: DPP moves (quad swaps, row shifts, row broadcasts) and one
+// readlane of lane 63 -- an xor butterfly of 64-bit values is twelve LDS-crossbar permutes per call, and the selection
+// makes K calls per chunk.  The kernel is VALU-bound on its 64-bit compare/select chains (~190 instructions per round),
+// which is why the host only picks it for the small levels (pcf_cuda.KNN_WAVE_MAX_WORK).
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_min_u64(unsigned long long v) {
+    const unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, 0xf, 0xf, false);
+    const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, 0xf, 0xf, false);
+    const unsigned long long o = ((unsigned long long)ohi << 32) | olo;     // lanes without a source keep their own value
+    return o < v ? o : v;
+}
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+    v = dpp_min_u64<0xb1>(v);     // quad_perm [1,0,3,2]
+    v = dpp_min_u64<0x4e>(v);     // quad_perm [2,3,0,1]
+    v = dpp_min_u64<0x114>(v);    // row_shr:4
+    v = dpp_min_u64<0x118>(v);    // row_shr:8   -> lane 15 of every row holds the row's minimum
+    v = dpp_min_u64<0x142>(v);    // row_bcast:15 -> lanes of rows 1..3 see the previous row's lane 15
+    v = dpp_min_u64<0x143>(v);    // row_bcast:31 -> lane 63 holds the minimum of the wave
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, WAVE - 1);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), WAVE - 1);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+__global__ __launch_bounds__(BLOCK) void knn_wave_kernel(const float* __restrict__ ref, const float* __restrict__ query,
+                                                         const int32_t* __restrict__ ref_off,
+                                                         const int32_t* __restrict__ query_off, int n_seg, int n_query,
+                                                         int K, int64_t* __restrict__ out) {
+    const int lane = lane_id();
+    for (int q = blockIdx.x * NWAVE + wave_id(); q < n_query; q += gridDim.x * NWAVE) {
+        int lo = 0, hi = n_seg;                              // query_off[lo] <= q < query_off[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (query_off[mid] <= q) lo = mid; else hi = mid;
+        }
+        const int r0 = ref_off[lo], r1 = ref_off[lo + 1];
+        const float qx = query[3 * (size_t)q], qy = query[3 * (size_t)q + 1], qz = query[3 * (size_t)q + 2];
+        unsigned long long carry = KEY_NONE;                 // lane j < K: the j-th best so far
+        for (int c0 = r0; c0 < r1; c0 += WAVE * WPER) {
+            unsigned long long pool[WPER + 1];
+            float rx[WPER], ry[WPER], rz[WPER];
+#pragma unroll
+            for (int s = 0; s < WPER; ++s) {                 // unconditional (clamped) loads: all of them in flight at once
+                const float* p = ref + 3 * (size_t)min(c0 + s * WAVE + lane, r1 - 1);
+                rx[s] = p[0]; ry[s] = p[1]; rz[s] = p[2];
+            }
+            asm volatile("" ::: "memory");                   // keeps hipcc from sinking each load next to its use (2 in flight)
+#pragma unroll
+            for (int s = 0; s < WPER; ++s) {
+                const int j = c0 + s * WAVE + lane;
+                const float dx = __fsub_rn(rx[s], qx), dy = __fsub_rn(ry[s], qy), dz = __fsub_rn(rz[s], qz);
+                const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+                pool[s] = j < r1 ? (((unsigned long long)__float_as_uint(d) << 32) | (unsigned)j) : KEY_NONE;
+            }
+            pool[WPER] = carry;
+            unsigned long long next = KEY_NONE;
+            for (int j = 0; j < K; ++j) {
+                unsigned long long m = pool[0];
+#pragma unroll
+                for (int s = 1; s <= WPER; ++s) m = pool[s] < m ? pool[s] : m;
+                m = wave_min_u64(m);
+                if (m == KEY_NONE) break;                    // fewer than K candidates so far (wave-uniform)
+#pragma unroll
+                for (int s = 0; s <= WPER; ++s) pool[s] = pool[s] == m ? KEY_NONE : pool[s];
+                if (lane == j) next = m;
+            }
+            carry = next;
+        }
+        if (lane < K) out[(size_t)q * K + lane] = carry == KEY_NONE ? (int64_t)-1 : (int64_t)(unsigned)(carry & 0xffffffffu);
+    }
+}
+
 // =================================================================================================
 // CSR transpose
 // =================================================================================================
@@ -319,6 +403,19 @@ int pcf_hip_knn(const float* ref, const float* query, const int32_t* ref_off, co
     else if (K <= 32) hipLaunchKernelGGL(knn_kernel<32>, grid, dim3(BLOCK), 0, s, ref, query, ref_off, query_off, K, out);
     else hipLaunchKernelGGL(knn_kernel<64>, grid, dim3(BLOCK), 0, s, ref, query, ref_off, query_off, K, out);
     return check_launch("kNN");
+}
+
+int pcf_hip_knn_wave(const float* ref, const float* query, const int32_t* ref_off, const int32_t* query_off, int n_seg,
+                     int n_query, int K, int64_t* out, void* stream) {
+    using namespace pcf;
+    PCF_REQUIRE(K >= 1 && K <= 64, "knn_wave: K must be in [1,64] (got %d)", K);
+    PCF_REQUIRE(n_seg >= 0 && n_query >= 0, "knn_wave: negative size");
+    if (n_seg == 0 || n_query == 0) return ok();
+    PCF_REQUIRE(ref_off && query_off && query && out, "knn_wave: null pointer");
+    const int grid = std::min(ceil_div(n_query, NWAVE), 256 * 64);
+    hipLaunchKernelGGL(knn_wave_kernel, dim3(grid), dim3(BLOCK), 0, (hipStream_t)stream, ref, query, ref_off, query_off, n_seg,
+                       n_query, K, out);
+    return check_launch("kNN (wave per query)");
 }
 
 size_t pcf_hip_knn_inverse_workspace_bytes(int B, int Nq, int K, int total_points) {

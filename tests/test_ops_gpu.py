@@ -367,7 +367,7 @@ def _surface(n, rng, side=20.0):
 
 @pytest.mark.parametrize('case', ['volume', 'surface', 'cross', 'plane', 'line', 'duplicates', 'tiny_segments', 'k40'])
 def test_knn_grid_equals_bruteforce(device, case):
-    """The grid engine returns exactly what the brute-force engine returns (which the oracle pins):
+    """The grid and the wave-per-query engines return exactly what the brute-force engine returns (which the oracle pins):
     volumes, folded sheets, exactly planar / collinear clouds (degenerate grid axes), heavy
     duplicates (ties by index), queries outside the reference box, tiny samples inside a packed batch."""
     import pcf_cuda
@@ -394,6 +394,8 @@ def test_knn_grid_equals_bruteforce(device, case):
     brute = pcf_cuda.knn_packed(*args, method='brute').cpu().numpy()
     grid = pcf_cuda.knn_packed(*args, method='grid').cpu().numpy()
     np.testing.assert_array_equal(grid, brute)
+    wave = pcf_cuda.knn_packed(*args, method='wave').cpu().numpy()
+    np.testing.assert_array_equal(wave, brute)
 
 
 def test_knn_grid_bit_exact_vs_c_oracle_80k(device):
