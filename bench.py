@@ -294,7 +294,7 @@ def main():
     cfg['DETERMINISTIC_BACKWARD'] = bool(args.deterministic)
     layer = pcf_layers.PCFLayer(C_FEAT, C_FEAT, cfg, weightnet=[12, C_MID], num_heads=HEADS,
                                 guidance_feat_len=GUID).to(dev).train()
-    model = pcf_dist.wrap_ddp(layer, dev)
+    model = layer          # N > 1: gradients are averaged through pcf_dist.GradBucket, or DDP when the steps run eagerly
 
     n = args.points
     xyz, nrm, feats = synth_cloud(n, seed=pcf_dist.data_seed(1, rank))
@@ -317,10 +317,28 @@ def main():
     csr_ms = (time.perf_counter() - t0) * 1e3
 
     params = list(layer.parameters())        # walking the module tree every step costs ~0.1 ms of host time
+    # N > 1: one flat bucket of the 13.7 k gradient floats, packed inside the replayed graph, one RCCL all-reduce and
+    # one multi-tensor copy back per step (DDP's per-step hooks need eager launches: ~20 % slower steps)
+    bucket = pcf_dist.GradBucket(params) if (world > 1 and not args.no_graph) else None
+    if bucket is not None:
+        bucket.broadcast_parameters()
+    elif world > 1:
+        model = pcf_dist.wrap_ddp(layer, dev)
 
-    def step():
+    def forward_backward():
         out, _ = model(xyz, feats, idx, nrm, None, None, None, inv_n, inv_k, inv_idx)
         out.sum().backward()
+
+    def sync_gradients():
+        if bucket is not None:
+            bucket.all_reduce()
+            bucket.unpack()
+
+    def step():
+        forward_backward()
+        if bucket is not None:
+            bucket.pack()
+        sync_gradients()
         for p in params:
             p.grad = None
         feats.grad = None
@@ -329,30 +347,51 @@ def main():
         step()
     eager_step = step
     graph = None
-    if world == 1 and not args.no_graph:
+    if not args.no_graph and (world == 1 or bucket is not None):
         # HIP graph of one whole step: ~190 kernel launches, memsets and allocations replayed with one call.
         # Same kernels, same order, same work; only the host-side launch cost leaves the timed region.
-        try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(3):
-                    step()
-            torch.cuda.current_stream().wait_stream(side)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                out_g, _ = model(xyz, feats, idx, nrm, None, None, None, inv_n, inv_k, inv_idx)
-                out_g.sum().backward()
+        captured = True
+        quiet = getattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch', None)
+        if quiet is not None:          # warm-up runs on a side stream by design (graph capture rules)
+            quiet(False)
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
             for _ in range(3):
-                g.replay()
-            torch.cuda.synchronize()
-            graph, step = g, g.replay
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()       # no collective in flight (its watchdog polls events) while the capture runs
+        try:
+            # N > 1: other threads of the process (the collective library's watchdog) may touch the runtime during capture
+            mode = {} if world == 1 else {'capture_error_mode': 'thread_local'}
+            with torch.cuda.graph(g, **mode):
+                forward_backward()
+                if bucket is not None:
+                    bucket.pack()
         except Exception as exc:       # capture is an optimisation of the measurement, not a requirement
             if args.graph:
                 raise
             print(f'bench: HIP-graph capture failed ({type(exc).__name__}: {exc}); timing eager steps', file=sys.stderr)
-            graph, step = None, eager_step
+            captured = False
+        torch.cuda.synchronize()
+        if world > 1:                  # every rank replays, or none does -- agreed before the next gradient collective
+            flag = torch.tensor([1 if captured else 0], dtype=torch.int32, device=dev)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+            captured = bool(flag.item())
+
+        def replay_step():
+            g.replay()
+            sync_gradients()
+
+        if captured:
+            for _ in range(3):
+                replay_step()
             torch.cuda.synchronize()
+        if captured:
+            graph, step = g, replay_step
+        else:
+            graph, step = None, eager_step
 
     fence = lambda: pcf_dist.fence(dev)
 
@@ -427,6 +466,7 @@ def main():
             'hip_ms_per_call': {k: round(v, 4) for k, v in sorted(hip_ms_all.items())},
             'hip_ms_per_step': round(hip_total_ms, 4),
             'knn_ms': round(knn_ms, 3), 'csr_ms': round(csr_ms, 3), 'hip_graph': graph is not None,
+            'grad_sync': None if world == 1 else ('one flat-bucket all-reduce per step' if bucket is not None else 'DistributedDataParallel'),
         }
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(layer.state_dict(), xyz, nrm, feats.detach(), idx)

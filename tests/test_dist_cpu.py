@@ -81,6 +81,14 @@ def _worker(rank, world, port, out):
     model(xyz, feats, idx, nrm).sum().backward()
     pcf_dist.fence(dev)
     grads = {n: p.grad.numpy().copy() for n, p in model.module.layer.named_parameters()}   # by value
+    # the same average through the flat bucket that the HIP-graph replayed steps use instead of DDP's hooks
+    plain = OracleDriven(_build())
+    bucket = pcf_dist.GradBucket(plain.parameters())
+    bucket.broadcast_parameters()
+    plain(xyz, feats, idx, nrm).sum().backward()
+    bucket.pack(); bucket.all_reduce(); bucket.unpack()
+    for (n, p), (_, q) in zip(plain.layer.named_parameters(), model.module.layer.named_parameters()):
+        torch.testing.assert_close(p.grad, q.grad, rtol=1e-6, atol=1e-7, msg=lambda m, n=n: f'bucket vs DDP {n}: {m}')
     slow = pcf_dist.max_over_ranks(1.0 + rank, dev)
     out.put((rank, grads, slow, pcf_dist.whole_job_rate(96, 3, world, slow)))
     pcf_dist.shutdown()
