@@ -7,8 +7,9 @@ Same class names, constructor arguments, ``forward`` signatures, sub-module name
   * ``layer_utils.py``  : ``index_points`` :13-30, ``PConvLinearOpt{,Function}`` :42-86,
                           ``PCF{,Function}`` :89-124, ``PConv{,Function}`` :127-173,
                           ``VI_coordinate_transform`` :176-231, ``Linear_BN`` :241-277, ``UnaryBlock`` :281-319
-  * ``layers.py``       : ``MultiHeadGuidance`` :23-68, ``WeightNet`` :127-191, ``PCFLayer`` :194-416,
-                          ``PointConvStridePE`` :542-741, ``PointConv`` :744-906, ``PointConvTransposePE`` :909-1105
+  * ``layers.py``       : ``MultiHeadGuidance`` :23-68, ``MultiHeadGuidanceQK`` :77-114, ``WeightNet`` :127-191,
+                          ``PCFLayer`` :194-416, ``PointTransformerLayer`` :419-539, ``PointConvStridePE`` :542-741,
+                          ``PointConv`` :744-906, ``PointConvTransposePE`` :909-1105
 
 but every neighbourhood operation goes to the HIP kernels behind ``pcf_cuda`` / ``pcf_fused``:
 this module never gathers with advanced indexing and has no PyTorch fallback for the aggregate --
@@ -229,15 +230,20 @@ class MultiHeadGuidance(pcf_fused.CounterScope):
 
     def __init__(self, cfg, num_heads: int, num_hiddens: int):
         super().__init__()
-        if getattr(cfg, 'layer_norm_guidance', False):
-            raise NotImplementedError('layer_norm_guidance=True is outside the hot path (SURVEY.md 8f-4)')
         self.num_heads, self.dim = num_heads, num_hiddens
+        ln = bool(getattr(cfg, 'layer_norm_guidance', False))       # ablation switch, False in every BASELINE config
+        self.layer_norm_q = nn.LayerNorm(num_hiddens) if ln else nn.Identity()
+        self.layer_norm_k = nn.LayerNorm(num_hiddens) if ln else nn.Identity()
         dims = [num_hiddens, 8, num_heads]
         self.mlp = nn.ModuleList(
             Linear_BN(a, b) if cfg.BATCH_NORM else nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
 
+    @property
+    def layer_norm(self):
+        return isinstance(self.layer_norm_q, nn.LayerNorm)
+
     def forward(self, guidance_query, guidance_key):
-        return self.forward_diff(guidance_query - guidance_key)
+        return self.forward_diff(self.layer_norm_q(guidance_query) - self.layer_norm_k(guidance_key))
 
     def forward_split(self, guidance_x, nei_inds, feat_pe):
         """Scores for SELF neighbourhoods (key = neighbour 0) without forming the query tensor.
@@ -265,6 +271,30 @@ class MultiHeadGuidance(pcf_fused.CounterScope):
         for i, layer in enumerate(self.mlp):
             s = _linear_act(layer, s, pcf_fused.ACT_SIGMOID if i == last else pcf_fused.ACT_RELU)
         return s
+
+
+class MultiHeadGuidanceQK(pcf_fused.CounterScope):
+    """sigmoid(scale * <W q, W key>) per head -- the inner-product form of the guidance, an ablation no BASELINE config
+    uses (layers.py:77-114; selected by cfg.attention_type != 'subtraction', :264-269).  The same Linear_BN runs over
+    the query tensor and over the key tensor repeated K times (two BatchNorm calls, each with its own batch statistics,
+    exactly as upstream); both go through the contraction + column-BatchNorm kernels, the per-head dot product and
+    the sigmoid are element-wise torch ops."""
+
+    def __init__(self, cfg, num_heads: int, num_hiddens: int, key_dim: int):
+        super().__init__()
+        assert num_hiddens % num_heads == 0, 'num_hiddens: %d, num_heads: %d' % (num_hiddens, num_heads)
+        self.cfg, self.dim, self.num_heads, self.key_dim = cfg, num_hiddens, num_heads, key_dim
+        self.scale = key_dim ** -0.5
+        self.qk_linear = Linear_BN(self.dim, key_dim * num_heads)
+
+    def forward(self, q, k):
+        """q [B,N,K,C]; k [B,N,K,C] or [B,N,1,C] (one centre row per neighbourhood) -> scores [B,N,K,heads]."""
+        B, N, K, _ = q.shape
+        if k.shape[2] != K:
+            k = k.expand(-1, -1, K, -1)
+        qq = self.qk_linear(q.contiguous()).view(B, N, K, self.num_heads, -1)
+        kk = self.qk_linear(k.contiguous()).view(B, N, K, self.num_heads, -1)[:, :, :1]
+        return torch.sigmoid((qq * kk).sum(-1) * self.scale)
 
 
 class WeightNet(pcf_fused.CounterScope):
@@ -314,8 +344,6 @@ class PCFLayer(pcf_fused.CounterScope):
 
     def __init__(self, in_channel, out_channel, cfg, weightnet=[9, 16], num_heads=4, guidance_feat_len=32):
         super().__init__()
-        if cfg.attention_type != 'subtraction':
-            raise NotImplementedError('QK guidance is outside the hot path (SURVEY.md 8f-4)')
         self.cfg, self.in_channel, self.out_channel, self.num_heads = cfg, in_channel, out_channel, num_heads
         self.drop_path = _drop_path(cfg)
         self._zero8 = torch.zeros(8)        # bias of the per-point half of the first guidance layer (not a parameter / buffer)
@@ -324,7 +352,8 @@ class PCFLayer(pcf_fused.CounterScope):
         self.unary1 = UnaryBlock(in_channel, mid, use_bn=True, bn_momentum=0.1) if in_channel != mid else nn.Identity()
         self.guidance_unary = UnaryBlock(mid, guidance_feat_len, use_bn=True, bn_momentum=0.1, no_relu=True)
         assert (out_channel // 2) % num_heads == 0
-        self.guidance_weight = MultiHeadGuidance(cfg, num_heads, 2 * guidance_feat_len)
+        self.guidance_weight = MultiHeadGuidance(cfg, num_heads, 2 * guidance_feat_len) \
+            if cfg.attention_type == 'subtraction' else MultiHeadGuidanceQK(cfg, num_heads, 2 * guidance_feat_len, key_dim=16)
         self.weightnet = WeightNet(weightnet[0], weightnet[1], efficient=True)
         self.linear = Linear_BN(mid * weightnet[-1], out_channel // 2, bn_ver='1d') if cfg.BATCH_NORM \
             else nn.Linear(mid * weightnet[-1], out_channel // 2)
@@ -336,7 +365,8 @@ class PCFLayer(pcf_fused.CounterScope):
     def _chain_layers(self, wn_in, nei_inds):
         """The six (Linear, BatchNorm) pairs of the edge graph if the fused chain kernel covers this layer
         (csrc/edge_chain.hip), else None."""
-        if getattr(self.cfg, 'NO_EDGE_CHAIN', False) or getattr(self.cfg, 'DETERMINISTIC_BACKWARD', False):
+        if getattr(self.cfg, 'NO_EDGE_CHAIN', False) or getattr(self.cfg, 'DETERMINISTIC_BACKWARD', False) \
+                or not isinstance(self.guidance_weight, MultiHeadGuidance) or self.guidance_weight.layer_norm:
             return None
         gw, wn = self.guidance_weight.mlp, self.weightnet.mlp_convs
         mods = [self.mlp_conv] + list(gw) + list(wn)
@@ -374,7 +404,12 @@ class PCFLayer(pcf_fused.CounterScope):
                                       g1_positional_weight=Wb)
         else:
             feat_pe = _linear_act(self.mlp_conv, wn_in, pcf_fused.ACT_RELU)
-            if not strided and pcf_fused.split_guidance_supported(nei_inds.shape[2], 8) \
+            if isinstance(self.guidance_weight, MultiHeadGuidanceQK) or self.guidance_weight.layer_norm:
+                # ablations (layers.py:370-381): the query tensor is formed, the key is its centre row / maximum over K
+                query = torch.cat([pcf_fused.gather_rows(guidance_x.contiguous(), nei_inds), feat_pe], -1)
+                key = query.max(dim=2, keepdim=True)[0] if strided else query[:, :, :1]
+                guidance_score = self.guidance_weight(query, key)
+            elif not strided and pcf_fused.split_guidance_supported(nei_inds.shape[2], 8) \
                     and pcf_fused.rowlin_supported(feat_pe.shape[-1], 8):
                 # self neighbourhoods: key = neighbour 0; the first guidance layer absorbs the q - key algebra
                 guidance_score = self.guidance_weight.forward_split(guidance_x.contiguous(), nei_inds, feat_pe)
@@ -393,6 +428,51 @@ class PCFLayer(pcf_fused.CounterScope):
         new_feat = self.unary2.forward_residual(self.dropout(_linear_act(self.linear, agg, pcf_fused.ACT_RELU)), shortcut,
                                                 pcf_fused.ACT_LEAKY)
         return new_feat, wn_in
+
+
+class PointTransformerLayer(pcf_fused.CounterScope):
+    """PointTransformer block, the reference's ablation against PCFLayer (layers.py:419-539; selected by
+    cfg.transformer_type != 'PCF', model_architecture.py:138-176): vector attention over the K neighbours with a
+    softmax, positional term from the coordinate offsets.  Same sub-module names as upstream (state_dicts load
+    unchanged).  Linears, BatchNorms, gathers and the coordinate offsets run on the HIP kernels of the hot path; the
+    softmax over K and the weighted sum are torch ops (this block is not on any BASELINE config's path)."""
+
+    def __init__(self, in_planes, out_planes, share_planes=8):
+        super().__init__()
+        self.mid_planes = mid_planes = out_planes // 1
+        self.out_planes, self.share_planes = out_planes, share_planes
+        self.linear_q = nn.Linear(in_planes, mid_planes)
+        self.linear_k = nn.Linear(in_planes, mid_planes)
+        self.linear_v = nn.Linear(in_planes, out_planes)
+        self.linear_p = nn.Sequential(Linear_BN(3, 3, bn_ver='1d'), nn.ReLU(inplace=True), nn.Linear(3, out_planes))
+        self.bn_w = nn.BatchNorm1d(mid_planes)
+        self.linear_w = nn.Sequential(nn.ReLU(inplace=True), Linear_BN(mid_planes, mid_planes // share_planes, bn_ver='1d'),
+                                      nn.ReLU(inplace=True), nn.Linear(mid_planes // share_planes, out_planes // share_planes))
+        self.unary_shortcut = UnaryBlock(in_planes, out_planes, use_bn=True, bn_momentum=0.1, no_relu=True) \
+            if in_planes != out_planes else nn.Identity()
+
+    def forward(self, xyz, feats, nei_ind, sparse_xyz=None):
+        strided = sparse_xyz is not None
+        nei_ind = nei_ind.contiguous()
+        B, M, K = nei_ind.shape
+        feats = feats.contiguous()
+        feats_q = _linear_act(self.linear_q, feats, pcf_fused.ACT_NONE)
+        feats_k = pcf_fused.gather_rows(_linear_act(self.linear_k, feats, pcf_fused.ACT_NONE), nei_ind)     # [B,M,K,mid]
+        feats_v = pcf_fused.gather_rows(_linear_act(self.linear_v, feats, pcf_fused.ACT_NONE), nei_ind)     # [B,M,K,out]
+        if strided:
+            feats_q = pcf_fused.gather_rows(feats_q, nei_ind[:, :, :1].contiguous())                        # [B,M,1,mid]
+        else:
+            feats_q = feats_q[:, :, None]
+        dxyz, _ = pcf_fused.edge_geometry(xyz, None, nei_ind, sparse_xyz if strided else xyz, None)           # xyz[idx] - centre
+        dxyz = _linear_act(self.linear_p[2], self.linear_p[0](dxyz, pcf_fused.ACT_RELU), pcf_fused.ACT_NONE)  # [B,M,K,out]
+        w = feats_k - feats_q + dxyz.view(B, M, K, self.out_planes // self.mid_planes, self.mid_planes).sum(3)
+        w = pcf_fused.bn_act(w, self.bn_w, pcf_fused.ACT_RELU, self.training)        # BatchNorm1d over (M, K) + the first ReLU
+        w = _linear_act(self.linear_w[3], self.linear_w[1](w, pcf_fused.ACT_RELU), pcf_fused.ACT_NONE)
+        w = torch.softmax(w, dim=2)                                                   # over the K neighbours
+        s, c = self.share_planes, self.out_planes
+        new_feats = ((feats_v + dxyz).view(B, M, K, s, c // s) * w.unsqueeze(3)).sum(2).view(B, M, c)
+        sparse_feats = pcf_fused.gather_max(feats, nei_ind) if strided else feats
+        return F.leaky_relu(new_feats + self.unary_shortcut(sparse_feats), 0.1)
 
 
 class _ConvTail(pcf_fused.CounterScope):

@@ -13,8 +13,8 @@ loads with ``strict=True``.  The graph is the reference's:
   decoder          PointConvTransposePE on edges_propagate[level] with the encoder skip
   head             Linear_BN + ReLU + Linear
 
-Only the PCF transformer type is built (PointTransformerLayer is an ablation outside the hot path,
-SURVEY.md 8f-4).  ``PCONV_OPT`` and ``USE_CUDA_KERNEL`` are given defaults here (the reference leaves
+``cfg.transformer_type`` other than 'PCF' builds the PointTransformerLayer ablation blocks in the guided levels
+(model_architecture.py:138-176, 214-237).  ``PCONV_OPT`` and ``USE_CUDA_KERNEL`` are given defaults here (the reference leaves
 ``PCONV_OPT`` undefaulted and crashes on configs that omit it).
 """
 from __future__ import annotations
@@ -24,7 +24,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 import pcf_fused
-from pcf_layers import Linear_BN, PCFLayer, PointConv, PointConvStridePE, PointConvTransposePE, _linear_act
+from pcf_layers import (Linear_BN, PCFLayer, PointConv, PointConvStridePE, PointConvTransposePE, PointTransformerLayer,
+                        _linear_act)
 
 
 class Config(dict):
@@ -68,9 +69,9 @@ def _inv(triple, i):
 class PCF_Backbone(pcf_fused.CounterScope):
     def __init__(self, cfg, input_feat_dim=3):
         super().__init__()
-        if cfg.transformer_type != 'PCF':
-            raise NotImplementedError('only transformer_type "PCF" is on the hot path (SURVEY.md 8f-4)')
         self.cfg = cfg
+        self.point_transformer = cfg.transformer_type != 'PCF'
+
         self.total_level = cfg.num_level
         self.guided_level = cfg.guided_level
         self.input_feat_dim = input_feat_dim + 3 if cfg.USE_XYZ else input_feat_dim
@@ -90,7 +91,9 @@ class PCF_Backbone(pcf_fused.CounterScope):
             guided = i > self.guided_level
 
             def make(a, b):
-                return PCFLayer(a, b, cfg, wn, cfg.num_heads) if guided else PointConvStridePE(a, b, cfg, wn)
+                if not guided:
+                    return PointConvStridePE(a, b, cfg, wn)
+                return PointTransformerLayer(a, b, cfg.num_heads) if self.point_transformer else PCFLayer(a, b, cfg, wn, cfg.num_heads)
 
             self.pointconv.append(make(in_ch, out_ch))
             self.pointconv_res.append(nn.ModuleList(make(out_ch, out_ch) for _ in range(cfg.resblocks[i])))
@@ -111,10 +114,16 @@ class PCF_Backbone(pcf_fused.CounterScope):
         feats = [x]
         for i, down in enumerate(self.pointconv):
             af = _inv(inv_fwd, i) if self.cfg.PCONV_OPT else {}
-            x, _ = down(pointclouds[i], feats[-1], edges_forward[i], norms[i], pointclouds[i + 1], norms[i + 1], **af)
+            if isinstance(down, PointTransformerLayer):       # model_architecture.py:214-216
+                x = down(pointclouds[i], feats[-1], edges_forward[i], pointclouds[i + 1])
+            else:
+                x, _ = down(pointclouds[i], feats[-1], edges_forward[i], norms[i], pointclouds[i + 1], norms[i + 1], **af)
             vi = None          # neighbourhoods change with the resolution: recomputed by the first block
             a_self = _inv(inv_self, i + 1) if self.cfg.PCONV_OPT else {}
             for block in self.pointconv_res[i]:
+                if isinstance(block, PointTransformerLayer):  # :225-227
+                    x = block(pointclouds[i + 1], x, edges_self[i + 1])
+                    continue
                 x, vi_new = block(pointclouds[i + 1], x, edges_self[i + 1], norms[i + 1], vi_features=vi, **a_self)
                 vi = vi_new if vi is None else vi
             feats.append(x)

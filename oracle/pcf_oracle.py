@@ -281,7 +281,11 @@ def weightnet(x, P: Params):
 
 def guidance_scores(query, key, P: Params):
     """MultiHeadGuidance, subtraction form: sigmoid(MLP(q - k)), ReLU between layers.
-    (layers.py:47-68; layer_norm_guidance False)"""
+    (layers.py:47-68; with cfg.layer_norm_guidance a LayerNorm on the query and another on the key first)"""
+    if P.has('layer_norm_q.weight'):          # cfg.layer_norm_guidance (layers.py:33-36, 52-53)
+        C = query.shape[-1]
+        query = F.layer_norm(query, (C,), P['layer_norm_q.weight'], P['layer_norm_q.bias'])
+        key = F.layer_norm(key, (C,), P['layer_norm_k.weight'], P['layer_norm_k.bias'])
     s = query - key
     n = 0
     while P.has(f'mlp.{n}.c.weight') or P.has(f'mlp.{n}.weight'):
@@ -290,6 +294,19 @@ def guidance_scores(query, key, P: Params):
         s = maybe_linear_bn(s, P.sub(f'mlp.{i}'))
         s = torch.sigmoid(s) if i == n - 1 else F.relu(s)
     return s
+
+
+def guidance_scores_qk(query, key, P: Params, num_heads):
+    """MultiHeadGuidanceQK: sigmoid(scale * <W q, W k>) per head, the key being the neighbourhood's single centre row.
+    (layers.py:77-114)  The reference runs the SAME Linear_BN over the query tensor and over the key tensor repeated
+    K times (two BatchNorm calls, each with its own batch statistics); only key row 0 of the result is used."""
+    B, N, K, _ = query.shape
+    q = linear_bn(query, P.sub('qk_linear'))
+    k = linear_bn(key.expand(-1, -1, K, -1), P.sub('qk_linear'))
+    d = q.shape[-1] // num_heads
+    q = q.view(B, N, K, num_heads, d)
+    k = k.view(B, N, K, num_heads, d)[:, :, :1]
+    return torch.sigmoid((q * k).sum(-1) * d ** -0.5)
 
 
 def _geometry(dense_xyz, dense_norm, idx, sparse_xyz, sparse_norm, use_vi, vi=None):
@@ -315,7 +332,10 @@ def pcf_layer(P: Params, dense_xyz, dense_feats, idx, dense_norm, sparse_xyz=Non
     gx = unary_block(fx, P.sub('guidance_unary'), relu=False)
     q = torch.cat([gather_rows(gx, idx), pe], -1)
     key = q[:, :, :1] if M == N else q.max(2, keepdim=True)[0]
-    score = guidance_scores(q, key, P.sub('guidance_weight'))
+    if P.has('guidance_weight.qk_linear.c.weight'):         # cfg.attention_type != 'subtraction' (layers.py:264-269)
+        score = guidance_scores_qk(q, key, P.sub('guidance_weight'), num_heads)
+    else:
+        score = guidance_scores(q, key, P.sub('guidance_weight'))
     w = weightnet(wn_in, P.sub('weightnet'))
     agg = pcf_forward(fx, idx, score, w)
     y = F.relu(maybe_linear_bn(agg, P.sub('linear')))
@@ -324,6 +344,37 @@ def pcf_layer(P: Params, dense_xyz, dense_feats, idx, dense_norm, sparse_xyz=Non
     if P.has('unary_shortcut.mlp.c.weight'):
         short = unary_block(short, P.sub('unary_shortcut'), relu=False)
     return F.leaky_relu(y + short, 0.1), wn_in
+
+
+def point_transformer_layer(P: Params, xyz, feats, idx, sparse_xyz=None, share_planes=8):
+    """PointTransformerLayer.forward (the ablation block, layers.py:419-539): vector attention over the K neighbours
+    with a softmax, positional term from the coordinate offsets.  Returns new_feats [1, M, out_planes]."""
+    K = idx.shape[2]
+    fq = F.linear(feats, P['linear_q.weight'], P['linear_q.bias'])
+    fk = gather_rows(F.linear(feats, P['linear_k.weight'], P['linear_k.bias']), idx)[0]       # [M, K, mid]
+    fv = gather_rows(F.linear(feats, P['linear_v.weight'], P['linear_v.bias']), idx)[0]       # [M, K, out]
+    if sparse_xyz is not None:
+        dxyz = gather_rows(xyz, idx) - sparse_xyz[:, :, None]
+        fq = gather_rows(fq, idx[:, :, :1])                                                   # [1, M, 1, mid]
+    else:
+        dxyz = gather_rows(xyz, idx) - xyz[:, :, None]
+        fq = fq[:, :, None]
+    dxyz = dxyz[0]
+    M = dxyz.shape[0]
+    dxyz = F.relu(linear_bn(dxyz, P.sub('linear_p.0')))
+    dxyz = F.linear(dxyz, P['linear_p.2.weight'], P['linear_p.2.bias'])                      # [M, K, out]
+    mid, out = fk.shape[-1], fv.shape[-1]
+    w = fk - fq[0] + dxyz.view(M, K, out // mid, mid).sum(2)
+    w = F.relu(batchnorm_lastdim(w, P.sub('bn_w')))            # BatchNorm1d on [M, mid, K] == per channel over (M, K)
+    w = F.relu(linear_bn(w, P.sub('linear_w.1')))
+    w = F.linear(w, P['linear_w.3.weight'], P['linear_w.3.bias'])                             # [M, K, out / s]
+    w = torch.softmax(w, dim=1)
+    s = share_planes
+    new = ((fv + dxyz).view(M, K, s, out // s) * w.unsqueeze(2)).sum(1).view(M, out)
+    short = feats if sparse_xyz is None else gather_rows(feats, idx).max(2)[0]
+    if P.has('unary_shortcut.mlp.c.weight'):
+        short = unary_block(short, P.sub('unary_shortcut'), relu=False)
+    return F.leaky_relu(new + short, 0.1)
 
 
 def _fused_linear(P: Params, agg):

@@ -93,7 +93,7 @@ def _run_layer(name, layer, args, captures, gen, meta):
         feat_key = next(k for k in args if k.endswith('feats'))
         for attempt in range(50):
             seen = {}
-            h = mod.register_forward_hook(lambda m, i, o: seen.__setitem__('lin', o))
+            h = mod.register_forward_hook(lambda m, i, o: seen.__setitem__('lin', o.detach().clone()))   # before any in-place ReLU
             layer.train()
             state = {k: v.clone() for k, v in layer.state_dict().items()}
             with torch.no_grad():

@@ -100,6 +100,78 @@ def test_pcf_layer_matches_reference(device, name, ci, co, cm, heads, mode):
     _run(layer, g, device, ['dense_feats'], PCF_ORDER)
 
 
+@pytest.mark.parametrize('name,ci,co,cm,heads,extra', [
+    ('pcf_qk_self', 64, 64, 16, 8, dict(attention_type='qk')), ('pcf_qk_strided', 32, 64, 4, 4, dict(attention_type='qk')),
+    ('pcf_ln_self', 64, 64, 16, 8, dict(layer_norm_guidance=True)), ('pcf_ln_strided', 32, 64, 4, 4, dict(layer_norm_guidance=True))])
+def test_pcf_layer_guidance_ablations_match_reference(device, name, ci, co, cm, heads, extra):
+    """The guidance ablations -- inner-product form (cfg.attention_type != 'subtraction' -> MultiHeadGuidanceQK,
+    layers.py:77-114) and LayerNorm on query / key (cfg.layer_norm_guidance, :33-36) -- against the reference's PyTorch
+    path: reference state_dict loaded strictly; output, feature gradient, every parameter gradient."""
+    import pcf_layers
+    g = load_golden(name)
+    layer = pcf_layers.PCFLayer(ci, co, cfg(**extra), weightnet=[12, cm], num_heads=heads, guidance_feat_len=32)
+    if 'attention_type' in extra:
+        assert isinstance(layer.guidance_weight, pcf_layers.MultiHeadGuidanceQK)
+    else:
+        assert layer.guidance_weight.layer_norm
+    _run(layer, g, device, ['dense_feats'], PCF_ORDER)
+
+
+@pytest.mark.parametrize('name,ci,co', [('ptl_self', 32, 32), ('ptl_strided', 32, 64)])
+def test_point_transformer_layer_matches_reference(device, name, ci, co):
+    """PointTransformerLayer (the transformer_type ablation, layers.py:419-539) against the reference's PyTorch path."""
+    import pcf_layers
+    g = load_golden(name)
+    layer = pcf_layers.PointTransformerLayer(ci, co, 8)
+    layer.load_state_dict(split(g, 'sd.'), strict=True)
+    layer.to(device).train()
+    a = split(g, 'in.')
+    feats = a['feats'].to(device).requires_grad_(True)
+    sx = a['sparse_xyz'].to(device) if 'sparse_xyz' in a else None
+    out = layer(a['xyz'].to(device), feats, a['nei_ind'].to(device), sx)
+    torch.testing.assert_close(out.cpu(), g['out.new_feat'], **TOL)
+    out.backward(g['gup'].to(device))
+    torch.testing.assert_close(feats.grad.cpu(), g['gin.feats'], **TOL)
+    want = split(g, 'gsd.')
+    for pname, p in layer.named_parameters():
+        assert p.grad is not None and pname in want, pname
+        tol = dict(rtol=0, atol=5e-3) if pname.endswith('c.bias') else TOL     # zero gradient in front of a batch-stat BN
+        torch.testing.assert_close(p.grad.cpu(), want[pname], **tol, msg=lambda m, n=pname: f'{n}: {m}')
+    # the statistics the three BatchNorms tracked
+    for k, v in layer.state_dict().items():
+        if 'num_batches_tracked' in k:
+            assert int(v) == 1, k
+
+
+def test_backbone_builds_point_transformer_blocks(device):
+    """cfg.transformer_type != 'PCF' puts PointTransformerLayer blocks in the guided levels (model_architecture.py:138-176)
+    and the model runs forward + backward through them."""
+    import pcf_layers
+    import pcf_model
+    c = pcf_model.Config(dict(BATCH_NORM=True, USE_XYZ=True, USE_PE=True, point_dim=3, num_level=3, grid_size=[0.1, 0.2, 0.4],
+                              base_dim=16, feat_dim=[16, 32, 48], mid_dim=[4, 4, 4], mid_dim_back=1, guided_level=0, num_heads=4,
+                              resblocks=[0, 1, 1], resblocks_back=[0, 0, 0], K_self=[8] * 3, K_forward=[8] * 3, K_propagate=[8] * 3,
+                              num_classes=5, drop_path_rate=0., dropout_rate=0., dropout_fc=0., layer_norm_guidance=False,
+                              transformer_type='PointTransformer'))
+    pcf_model.get_default_configs(c, num_level=3, base_dim=16)
+    c.PCONV_OPT, c.USE_CUDA_KERNEL = True, True
+    torch.manual_seed(0)
+    net = pcf_model.PointConvFormer_Segmentation(c).to(device).train()
+    assert all(isinstance(m, pcf_layers.PointTransformerLayer) for m in net.pcf_backbone.pointconv)
+    import knn_post_dataloader_utils as U
+    g = torch.Generator().manual_seed(3)
+    xyz = torch.rand(1500, 3, generator=g).to(device)
+    nrm = torch.nn.functional.normalize(torch.randn(1500, 3, generator=g), dim=-1).to(device)
+    pcs, nrms, stored = U.subsample_packed(xyz, nrm, [900, 600], [0.05, 0.12, 0.3])
+    es, ef, ep = U.prepare(*U.compute_knn_packed(pcs, stored, c.K_self, c.K_forward, c.K_propagate))
+    inv = U.compute_knn_inverse(pcs, es, ef, ep)
+    feats = torch.randn(1, pcs[0].shape[1], 3, generator=g).to(device)
+    out = net(feats, pcs, es, ef, ep, nrms, *inv)
+    assert out.shape == (1, pcs[0].shape[1], 5) and torch.isfinite(out).all()
+    out.sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+
+
 # (4, 1001, 4): 4004 edges per cloud, so batch boundaries fall inside 16-edge tiles
 @pytest.mark.parametrize('B,N,K,cm,heads,gfl', [(2, 3000, 16, 16, 8, 32), (1, 4096, 8, 8, 4, 16), (3, 1000, 4, 16, 8, 20),
                                                 (4, 1001, 4, 4, 2, 8), (1, 64, 2, 16, 8, 32)])

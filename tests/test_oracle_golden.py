@@ -35,7 +35,8 @@ def _check_param_grads(g, sd):
         torch.testing.assert_close(got, v, **tol, msg=lambda m, k=k: f'{k}: {m}')
 
 
-@pytest.mark.parametrize('name', ['pcf_self_64', 'pcf_self_32_64', 'pcf_strided'])
+@pytest.mark.parametrize('name', ['pcf_self_64', 'pcf_self_32_64', 'pcf_strided', 'pcf_qk_self', 'pcf_qk_strided',
+                                  'pcf_ln_self', 'pcf_ln_strided'])
 def test_pcf_layer(name):
     g = load_golden(name)
     a = split(g, 'in.')
@@ -183,3 +184,18 @@ def test_knn_inverse_small_known_answer():
     assert inv_idx.tolist() == [0, 2, 4, 6]
     assert inv_n.tolist() == [0, 1, 0, 3, 1, 2, 0, 0]
     assert inv_k.tolist() == [0, 0, 1, 0, 1, 0, 0, 0]
+
+
+@pytest.mark.parametrize('name', ['ptl_self', 'ptl_strided'])
+def test_point_transformer_layer(name):
+    """The ablation block (layers.py:419-539) as the reference's PyTorch code computed it: output, feature gradient and
+    every parameter gradient."""
+    g = load_golden(name)
+    a = split(g, 'in.')
+    sd, P = _params(g)
+    feats = a['feats'].clone().requires_grad_(True)
+    out = O.point_transformer_layer(P, a['xyz'], feats, a['nei_ind'], a.get('sparse_xyz'), share_planes=8)
+    torch.testing.assert_close(out, g['out.new_feat'], **TOL)
+    out.backward(g['gup'])
+    torch.testing.assert_close(feats.grad, g['gin.feats'], **TOL)
+    _check_param_grads(g, sd)
