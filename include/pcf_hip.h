@@ -154,6 +154,17 @@ int pcf_hip_knn_grid(const float* ref, const float* query, const int32_t* ref_of
                      int n_seg, int n_ref, int n_query, int K, int64_t* out, void* workspace,
                      size_t workspace_bytes, void* stream);
 
+/* All neighbour tables of a training iteration transposed in one pass of launches (8 instead of 8 per table):
+ * replaces the call pattern of util/common_util.compute_knn_inverse (:281-309: one pcf_cuda.compute_knn_inverse per
+ * level and relation = 3 x levels calls per iteration).  Table i: idx[i] i64 [Nq[i], K[i]] -> inv_neighbors[i] i32
+ * [Nq[i]*K[i]], inv_k[i] u8 [Nq[i]*K[i]], inv_idx[i] i32 [total_points[i]+1]; same contents as pcf_hip_knn_inverse with
+ * B = 1 (buckets sorted by (query, k)).  The pointer and size lists are host arrays; every table must be non-empty
+ * (Nq >= 1, total_points >= 1). */
+size_t pcf_hip_knn_inverse_batched_workspace_bytes(int n_tables, const int* Nq, const int* K, const int* total_points);
+int pcf_hip_knn_inverse_batched(int n_tables, const int64_t* const* idx, int32_t* const* inv_neighbors,
+                                uint8_t* const* inv_k, int32_t* const* inv_idx, const int* Nq, const int* K,
+                                const int* total_points, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- multi-resolution levels: barycentre grid subsampling of a packed batch --------------------------
  * replaces cpp_subsampling.compute(points, features=..., sampleDl=..., method="barycenters")
  *   (cpp_wrappers/cpp_subsampling/wrapper.cpp:200-290 -> grid_subsampling/grid_subsampling.cpp:9-110),

@@ -14,6 +14,7 @@
 // order the atomics landed in.  Replaces count_neighbors / compute_inv_idx (a single-thread scan) /
 // fill_inverse of knn.cu:24-168, whose bucket order is run-to-run random.
 #include <algorithm>
+#include <vector>
 
 #include "pcf_common.h"
 
@@ -165,12 +166,16 @@ __global__ __launch_bounds__(BLOCK) void knn_wave_kernel(const float* __restrict
 // =================================================================================================
 // CSR transpose
 // =================================================================================================
-__global__ __launch_bounds__(BLOCK) void csr_count_kernel(const int64_t* __restrict__ idx, int32_t* __restrict__ counts,
-                                                          long long edges, int total_points) {
-    for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < edges; e += (long long)gridDim.x * BLOCK) {
+__device__ __forceinline__ void csr_count_body(const int64_t* __restrict__ idx, int32_t* __restrict__ counts,
+                                                          long long edges, int total_points, int bx, int gx) {
+    for (long long e = (long long)bx * BLOCK + threadIdx.x; e < edges; e += (long long)gx * BLOCK) {
         const int64_t t = idx[e];
         if (t >= 0 && t < total_points) atomicAdd(&counts[t], 1);
     }
+}
+__global__ __launch_bounds__(BLOCK) void csr_count_kernel(const int64_t* __restrict__ idx, int32_t* __restrict__ counts,
+                                                          long long edges, int total_points) {
+    csr_count_body(idx, counts, edges, total_points, blockIdx.x, gridDim.x);
 }
 
 constexpr int SCAN_CHUNK = 1024;   // elements per workgroup (4 per thread)
@@ -199,20 +204,24 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* total) {
 }
 
 // phase a: per-chunk totals
-__global__ __launch_bounds__(BLOCK) void scan_chunk_sums_kernel(const int32_t* __restrict__ counts,
-                                                                int32_t* __restrict__ chunk_sums, int n) {
-    const int base = blockIdx.x * SCAN_CHUNK + threadIdx.x * 4;
+__device__ __forceinline__ void scan_chunk_sums_body(const int32_t* __restrict__ counts,
+                                                                int32_t* __restrict__ chunk_sums, int n, int bx, int gx) {
+    const int base = bx * SCAN_CHUNK + threadIdx.x * 4;
     int v = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
         if (base + i < n) v += counts[base + i];
     int total;
     block_exclusive_scan(v, &total);
-    if (threadIdx.x == 0) chunk_sums[blockIdx.x] = total;
+    if (threadIdx.x == 0) chunk_sums[bx] = total;
+}
+__global__ __launch_bounds__(BLOCK) void scan_chunk_sums_kernel(const int32_t* __restrict__ counts,
+                                                                int32_t* __restrict__ chunk_sums, int n) {
+    scan_chunk_sums_body(counts, chunk_sums, n, blockIdx.x, gridDim.x);
 }
 
 // phase b: exclusive scan of the chunk totals by one workgroup
-__global__ __launch_bounds__(BLOCK) void scan_chunk_offsets_kernel(int32_t* __restrict__ chunk_sums, int nchunks) {
+__device__ __forceinline__ void scan_chunk_offsets_body(int32_t* __restrict__ chunk_sums, int nchunks, int bx, int gx) {
     __shared__ int carry;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
@@ -228,13 +237,16 @@ __global__ __launch_bounds__(BLOCK) void scan_chunk_offsets_kernel(int32_t* __re
         __syncthreads();
     }
 }
+__global__ __launch_bounds__(BLOCK) void scan_chunk_offsets_kernel(int32_t* __restrict__ chunk_sums, int nchunks) {
+    scan_chunk_offsets_body(chunk_sums, nchunks, blockIdx.x, gridDim.x);
+}
 
 // phase c: inv_idx[i] = exclusive prefix of counts; inv_idx[n] = grand total.  `clear` leaves counts zeroed for its
 // second life as the per-bucket cursor of the fill pass (saves a memset launch per call).
-__global__ __launch_bounds__(BLOCK) void scan_write_kernel(int32_t* __restrict__ counts,
+__device__ __forceinline__ void scan_write_body(int32_t* __restrict__ counts,
                                                            const int32_t* __restrict__ chunk_offsets,
-                                                           int32_t* __restrict__ inv_idx, int n, bool clear) {
-    const int base = blockIdx.x * SCAN_CHUNK + threadIdx.x * 4;
+                                                           int32_t* __restrict__ inv_idx, int n, bool clear, int bx, int gx) {
+    const int base = bx * SCAN_CHUNK + threadIdx.x * 4;
     int c[4];
     int v = 0;
 #pragma unroll
@@ -244,13 +256,18 @@ __global__ __launch_bounds__(BLOCK) void scan_write_kernel(int32_t* __restrict__
         if (clear && base + i < n) counts[base + i] = 0;
     }
     int total;
-    int run = chunk_offsets[blockIdx.x] + block_exclusive_scan(v, &total);
+    int run = chunk_offsets[bx] + block_exclusive_scan(v, &total);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         if (base + i < n) inv_idx[base + i] = run;
         run += c[i];
         if (base + i == n - 1) inv_idx[n] = run;
     }
+}
+__global__ __launch_bounds__(BLOCK) void scan_write_kernel(int32_t* __restrict__ counts,
+                                                           const int32_t* __restrict__ chunk_offsets,
+                                                           int32_t* __restrict__ inv_idx, int n, bool clear) {
+    scan_write_body(counts, chunk_offsets, inv_idx, n, clear, blockIdx.x, gridDim.x);
 }
 
 // out[i] = sum of counts[0..i) for i in [0, n]; chunk_tmp holds ceil(n / 1024) ints.  (also used by knn_grid.hip)
@@ -266,17 +283,23 @@ int exclusive_scan_i32(int32_t* counts, int32_t* chunk_tmp, int32_t* out, int n,
     return check_launch("exclusive scan");
 }
 
-__global__ __launch_bounds__(BLOCK) void csr_fill_kernel(const int64_t* __restrict__ idx,
+__device__ __forceinline__ void csr_fill_body(const int64_t* __restrict__ idx,
                                                          const int32_t* __restrict__ inv_idx,
                                                          int32_t* __restrict__ cursor, uint32_t* __restrict__ keys,
-                                                         long long edges, int total_points) {
-    for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < edges; e += (long long)gridDim.x * BLOCK) {
+                                                         long long edges, int total_points, int bx, int gx) {
+    for (long long e = (long long)bx * BLOCK + threadIdx.x; e < edges; e += (long long)gx * BLOCK) {
         const int64_t t = idx[e];
         if (t >= 0 && t < total_points) {
             const int pos = atomicAdd(&cursor[t], 1);
             keys[inv_idx[t] + pos] = (uint32_t)e;
         }
     }
+}
+__global__ __launch_bounds__(BLOCK) void csr_fill_kernel(const int64_t* __restrict__ idx,
+                                                         const int32_t* __restrict__ inv_idx,
+                                                         int32_t* __restrict__ cursor, uint32_t* __restrict__ keys,
+                                                         long long edges, int total_points) {
+    csr_fill_body(idx, inv_idx, cursor, keys, edges, total_points, blockIdx.x, gridDim.x);
 }
 
 __device__ __forceinline__ void emit(uint32_t key, int pos, int K, int32_t* inv_n, uint8_t* inv_k) {
@@ -287,19 +310,19 @@ __device__ __forceinline__ void emit(uint32_t key, int pos, int K, int32_t* inv_
 
 // Buckets of <= 64 entries: one wave each, bitonic network over the lanes.  Larger buckets are
 // appended to a work list for csr_sort_large_kernel.
-__global__ __launch_bounds__(BLOCK) void csr_sort_small_kernel(const uint32_t* __restrict__ keys,
+__device__ __forceinline__ void csr_sort_small_body(const uint32_t* __restrict__ keys,
                                                                const int32_t* __restrict__ inv_idx, int total_points,
                                                                int K, int32_t* __restrict__ inv_n,
                                                                uint8_t* __restrict__ inv_k, int32_t* __restrict__ big_list,
-                                                               int32_t* __restrict__ big_count, long long edges) {
+                                                               int32_t* __restrict__ big_count, long long edges, int bx, int gx) {
     const int lane = lane_id();
     // slots past the last valid edge (out-of-range neighbour indices leave some) read as zero
-    for (long long e = inv_idx[total_points] + (long long)blockIdx.x * BLOCK + threadIdx.x; e < edges;
-         e += (long long)gridDim.x * BLOCK) {
+    for (long long e = inv_idx[total_points] + (long long)bx * BLOCK + threadIdx.x; e < edges;
+         e += (long long)gx * BLOCK) {
         inv_n[e] = 0;
         inv_k[e] = 0;
     }
-    for (int t = blockIdx.x * NWAVE + wave_id(); t < total_points; t += gridDim.x * NWAVE) {
+    for (int t = bx * NWAVE + wave_id(); t < total_points; t += gx * NWAVE) {
         const int beg = inv_idx[t], end = inv_idx[t + 1];
         const int d = end - beg;
         if (d <= 0) continue;
@@ -321,19 +344,26 @@ __global__ __launch_bounds__(BLOCK) void csr_sort_small_kernel(const uint32_t* _
         if (lane < d) emit(v, beg + lane, K, inv_n, inv_k);
     }
 }
+__global__ __launch_bounds__(BLOCK) void csr_sort_small_kernel(const uint32_t* __restrict__ keys,
+                                                               const int32_t* __restrict__ inv_idx, int total_points,
+                                                               int K, int32_t* __restrict__ inv_n,
+                                                               uint8_t* __restrict__ inv_k, int32_t* __restrict__ big_list,
+                                                               int32_t* __restrict__ big_count, long long edges) {
+    csr_sort_small_body(keys, inv_idx, total_points, K, inv_n, inv_k, big_list, big_count, edges, blockIdx.x, gridDim.x);
+}
 
 constexpr int SORT_LDS = 4096;   // keys a workgroup sorts in LDS
 
 // Buckets of > 64 entries: one workgroup each.  Up to SORT_LDS keys: bitonic sort in LDS.  Beyond
 // that (adversarial tables only): rank by counting, O(d^2 / 256) -- slow but exact.
-__global__ __launch_bounds__(BLOCK) void csr_sort_large_kernel(const uint32_t* __restrict__ keys,
+__device__ __forceinline__ void csr_sort_large_body(const uint32_t* __restrict__ keys,
                                                                const int32_t* __restrict__ inv_idx, int K,
                                                                int32_t* __restrict__ inv_n, uint8_t* __restrict__ inv_k,
                                                                const int32_t* __restrict__ big_list,
-                                                               const int32_t* __restrict__ big_count) {
+                                                               const int32_t* __restrict__ big_count, int bx, int gx) {
     __shared__ uint32_t s[SORT_LDS];
     const int nbig = *big_count;
-    for (int w = blockIdx.x; w < nbig; w += gridDim.x) {
+    for (int w = bx; w < nbig; w += gx) {
         const int t = big_list[w];
         const int beg = inv_idx[t], d = inv_idx[t + 1] - beg;
         if (d <= SORT_LDS) {
@@ -366,6 +396,13 @@ __global__ __launch_bounds__(BLOCK) void csr_sort_large_kernel(const uint32_t* _
         }
     }
 }
+__global__ __launch_bounds__(BLOCK) void csr_sort_large_kernel(const uint32_t* __restrict__ keys,
+                                                               const int32_t* __restrict__ inv_idx, int K,
+                                                               int32_t* __restrict__ inv_n, uint8_t* __restrict__ inv_k,
+                                                               const int32_t* __restrict__ big_list,
+                                                               const int32_t* __restrict__ big_count) {
+    csr_sort_large_body(keys, inv_idx, K, inv_n, inv_k, big_list, big_count, blockIdx.x, gridDim.x);
+}
 
 struct CsrWs {
     size_t off_counts, off_chunks, off_keys, off_big, off_bigcount, bytes;
@@ -380,6 +417,76 @@ static CsrWs csr_plan(int Nq, int K, int total_points) {
     w.off_keys = off;     off = align_up(off + (size_t)Nq * K * 4 + 4, 256);
     w.off_big = off;      off = align_up(off + (size_t)std::max(total_points, 1) * 4, 256);
     w.off_bigcount = w.off_counts + (size_t)std::max(total_points, 1) * 4;      // cleared with the counts in one memset
+    w.bytes = off;
+    return w;
+}
+
+
+// ---- all edge sets of an iteration in one pass of launches ----------------------------------------------------
+// A training iteration transposes 3 x levels neighbour tables (util/common_util.py:281-309: self, forward and
+// propagate edges of every level): 13 calls x 8 launches for the 10cm-lite model, most of them on tables too small to
+// fill the chip.  Here blockIdx.y picks the table and every phase runs once for all of them.
+constexpr int CSR_BATCH_MAX = 16;
+struct CsrProblem {
+    const int64_t* idx;
+    int32_t* nb;
+    uint8_t* kb;
+    int32_t* xb;
+    int32_t *counts, *chunks, *big, *bigc;
+    uint32_t* keys;
+    long long edges;
+    int total_points, K, nchunks;
+};
+struct CsrBatch { CsrProblem p[CSR_BATCH_MAX]; };
+
+__global__ __launch_bounds__(BLOCK) void csr_count_batch_kernel(const CsrBatch b) {
+    const CsrProblem& q = b.p[blockIdx.y];
+    csr_count_body(q.idx, q.counts, q.edges, q.total_points, blockIdx.x, gridDim.x);
+}
+__global__ __launch_bounds__(BLOCK) void scan_chunk_sums_batch_kernel(const CsrBatch b) {
+    const CsrProblem& q = b.p[blockIdx.y];
+    if ((int)blockIdx.x < q.nchunks) scan_chunk_sums_body(q.counts, q.chunks, q.total_points, blockIdx.x, gridDim.x);
+}
+__global__ __launch_bounds__(BLOCK) void scan_chunk_offsets_batch_kernel(const CsrBatch b) {
+    const CsrProblem& q = b.p[blockIdx.y];
+    scan_chunk_offsets_body(q.chunks, q.nchunks, 0, 1);
+}
+__global__ __launch_bounds__(BLOCK) void scan_write_batch_kernel(const CsrBatch b) {
+    const CsrProblem& q = b.p[blockIdx.y];
+    if ((int)blockIdx.x < q.nchunks) scan_write_body(q.counts, q.chunks, q.xb, q.total_points, true, blockIdx.x, gridDim.x);
+}
+__global__ __launch_bounds__(BLOCK) void csr_fill_batch_kernel(const CsrBatch b) {
+    const CsrProblem& q = b.p[blockIdx.y];
+    csr_fill_body(q.idx, q.xb, q.counts, q.keys, q.edges, q.total_points, blockIdx.x, gridDim.x);
+}
+__global__ __launch_bounds__(BLOCK) void csr_sort_small_batch_kernel(const CsrBatch b) {
+    const CsrProblem& q = b.p[blockIdx.y];
+    csr_sort_small_body(q.keys, q.xb, q.total_points, q.K, q.nb, q.kb, q.big, q.bigc, q.edges, blockIdx.x, gridDim.x);
+}
+__global__ __launch_bounds__(BLOCK) void csr_sort_large_batch_kernel(const CsrBatch b) {
+    const CsrProblem& q = b.p[blockIdx.y];
+    csr_sort_large_body(q.keys, q.xb, q.K, q.nb, q.kb, q.big, q.bigc, blockIdx.x, gridDim.x);
+}
+
+// workspace of a batch: [counts + big-bucket count of every table (zeroed by one memset)] [chunk sums, keys, big lists]
+struct CsrBatchWs { size_t zero_bytes, bytes; };
+static CsrBatchWs csr_batch_plan(int n, const int* Nq, const int* K, const int* total_points, size_t* off_counts,
+                                 size_t* off_chunks, size_t* off_keys, size_t* off_big) {
+    size_t off = 0;
+    for (int i = 0; i < n; ++i) {
+        if (off_counts) off_counts[i] = off;
+        off = align_up(off + ((size_t)std::max(total_points[i], 1) + 1) * 4, 256);
+    }
+    CsrBatchWs w{off, 0};
+    for (int i = 0; i < n; ++i) {
+        const int nchunks = std::max(1, ceil_div(total_points[i], SCAN_CHUNK));
+        if (off_chunks) off_chunks[i] = off;
+        off = align_up(off + (size_t)nchunks * 4, 256);
+        if (off_keys) off_keys[i] = off;
+        off = align_up(off + (size_t)Nq[i] * K[i] * 4 + 4, 256);
+        if (off_big) off_big[i] = off;
+        off = align_up(off + (size_t)std::max(total_points[i], 1) * 4, 256);
+    }
     w.bytes = off;
     return w;
 }
@@ -480,6 +587,70 @@ int pcf_hip_knn_inverse(const int64_t* idx, int32_t* inv_neighbors, uint8_t* inv
         }
     }
 #undef PCF_HIP
+    return ok();
+}
+
+
+size_t pcf_hip_knn_inverse_batched_workspace_bytes(int n_tables, const int* Nq, const int* K, const int* total_points) {
+    if (n_tables < 0 || (n_tables > 0 && (!Nq || !K || !total_points))) return 0;
+    for (int i = 0; i < n_tables; ++i)
+        if (Nq[i] < 0 || K[i] < 1 || total_points[i] < 0) return 0;
+    return pcf::csr_batch_plan(n_tables, Nq, K, total_points, nullptr, nullptr, nullptr, nullptr).bytes;
+}
+
+int pcf_hip_knn_inverse_batched(int n_tables, const int64_t* const* idx, int32_t* const* inv_neighbors,
+                                uint8_t* const* inv_k, int32_t* const* inv_idx, const int* Nq, const int* K,
+                                const int* total_points, void* workspace, size_t workspace_bytes, void* stream) {
+    using namespace pcf;
+    PCF_REQUIRE(n_tables >= 0 && n_tables <= 4096, "knn_inverse_batched: bad table count %d", n_tables);
+    if (n_tables == 0) return ok();
+    PCF_REQUIRE(idx && inv_neighbors && inv_k && inv_idx && Nq && K && total_points, "knn_inverse_batched: null table list");
+    for (int i = 0; i < n_tables; ++i) {
+        PCF_REQUIRE(Nq[i] >= 1 && total_points[i] >= 1, "knn_inverse_batched: table %d is empty (Nq=%d, total_points=%d): "
+                    "use pcf_hip_knn_inverse for it", i, Nq[i], total_points[i]);
+        PCF_REQUIRE(K[i] >= 1 && K[i] <= 255, "knn_inverse_batched: K must be in [1,255] (inv_k is uint8), got %d", K[i]);
+        PCF_REQUIRE((long long)Nq[i] * K[i] < (1ll << 31), "knn_inverse_batched: Nq*K does not fit 31 bits");
+        PCF_REQUIRE(idx[i] && inv_neighbors[i] && inv_k[i] && inv_idx[i], "knn_inverse_batched: null pointer in table %d", i);
+    }
+    std::vector<size_t> oc(n_tables), och(n_tables), ok_(n_tables), ob(n_tables);
+    const CsrBatchWs w = csr_batch_plan(n_tables, Nq, K, total_points, oc.data(), och.data(), ok_.data(), ob.data());
+    PCF_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= w.bytes,
+                "knn_inverse_batched: workspace too small or misaligned (%zu < %zu)", workspace_bytes, w.bytes);
+    hipStream_t s = (hipStream_t)stream;
+    char* ws = static_cast<char*>(workspace);
+    if (hipMemsetAsync(ws, 0, w.zero_bytes, s) != hipSuccess) return fail(PCF_E_LAUNCH, "knn_inverse_batched: memset failed");
+    for (int base = 0; base < n_tables; base += CSR_BATCH_MAX) {
+        const int nb = std::min(CSR_BATCH_MAX, n_tables - base);
+        CsrBatch b{};
+        long long max_edges = 0;
+        int max_chunks = 1, max_points = 1;
+        for (int j = 0; j < nb; ++j) {
+            const int i = base + j;
+            CsrProblem& q = b.p[j];
+            q.idx = idx[i]; q.nb = inv_neighbors[i]; q.kb = inv_k[i]; q.xb = inv_idx[i];
+            q.counts = reinterpret_cast<int32_t*>(ws + oc[i]);
+            q.bigc = q.counts + total_points[i];
+            q.chunks = reinterpret_cast<int32_t*>(ws + och[i]);
+            q.keys = reinterpret_cast<uint32_t*>(ws + ok_[i]);
+            q.big = reinterpret_cast<int32_t*>(ws + ob[i]);
+            q.edges = (long long)Nq[i] * K[i];
+            q.total_points = total_points[i]; q.K = K[i];
+            q.nchunks = std::max(1, ceil_div(total_points[i], SCAN_CHUNK));
+            max_edges = std::max(max_edges, q.edges);
+            max_chunks = std::max(max_chunks, q.nchunks);
+            max_points = std::max(max_points, total_points[i]);
+        }
+        const int egrid = (int)std::max<long long>(1, std::min<long long>((max_edges + BLOCK - 1) / BLOCK, 4096));
+        const int sgrid = std::max(1, std::min(ceil_div(max_points, NWAVE), 8192));
+        hipLaunchKernelGGL(csr_count_batch_kernel, dim3(egrid, nb), dim3(BLOCK), 0, s, b);
+        hipLaunchKernelGGL(scan_chunk_sums_batch_kernel, dim3(max_chunks, nb), dim3(BLOCK), 0, s, b);
+        hipLaunchKernelGGL(scan_chunk_offsets_batch_kernel, dim3(1, nb), dim3(BLOCK), 0, s, b);
+        hipLaunchKernelGGL(scan_write_batch_kernel, dim3(max_chunks, nb), dim3(BLOCK), 0, s, b);
+        hipLaunchKernelGGL(csr_fill_batch_kernel, dim3(egrid, nb), dim3(BLOCK), 0, s, b);
+        hipLaunchKernelGGL(csr_sort_small_batch_kernel, dim3(sgrid, nb), dim3(BLOCK), 0, s, b);
+        hipLaunchKernelGGL(csr_sort_large_batch_kernel, dim3(256, nb), dim3(BLOCK), 0, s, b);
+        if (int e = check_launch("knn_inverse_batched")) return e;
+    }
     return ok();
 }
 

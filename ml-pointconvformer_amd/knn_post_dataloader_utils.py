@@ -169,15 +169,24 @@ def compute_knn_inverse(pointclouds, edges_self, edges_forward, edges_propagate)
     """CSR transposes of every edge set, as util/common_util.py:250-327 builds them (same return
     structure: three lists [inverse_neighbors, inverse_k, inverse_idx], each a list over levels).
     The reference's own function works unchanged on top of this package's ``pcf_cuda``; this copy
-    exists so that code using only this package does not need the reference's ``util`` package."""
-    def build(edge_list):
-        out = ([], [], [])
+    exists so that code using only this package does not need the reference's ``util`` package.
+    One pass of launches over all 3 x levels tables (pcf_cuda.compute_knn_inverse_batched) instead of one call per
+    table."""
+    lists = (edges_self, edges_forward, edges_propagate)
+    tables, totals = [], []
+    for edge_list in lists:
         for j, e in enumerate(edge_list):
-            inv = pcf_cuda.compute_knn_inverse(e.contiguous(), int(pointclouds[j].shape[1]))
-            for dst, t in zip(out, inv):
+            tables.append(e.contiguous())
+            totals.append(int(pointclouds[j].shape[1]))
+    inv = iter(pcf_cuda.compute_knn_inverse_batched(tables, totals))
+    result = []
+    for edge_list in lists:
+        out = ([], [], [])
+        for _ in edge_list:
+            for dst, t in zip(out, next(inv)):
                 dst.append(t)
-        return list(out)
-    return build(edges_self), build(edges_forward), build(edges_propagate)
+        result.append(list(out))
+    return tuple(result)
 
 
 def subsample_packed(coord, norm, points_stored0, grid_size, min_points=16):

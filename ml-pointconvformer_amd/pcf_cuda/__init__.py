@@ -72,6 +72,10 @@ _inv_ws = _sig('pcf_hip_knn_inverse_workspace_bytes', [_I] * 4, _Z)
 _inv = _sig('pcf_hip_knn_inverse', [_P] * 5 + [_Z] + [_I] * 4 + [_P])
 _knn = _sig('pcf_hip_knn', [_P] * 4 + [_I] * 3 + [_P] * 2)
 _knn_grid_ws = _sig('pcf_hip_knn_grid_workspace_bytes', [_I, _I], _Z)
+_IP = ctypes.POINTER(ctypes.c_int)
+_PP = ctypes.POINTER(ctypes.c_void_p)
+_inv_batch_ws = _sig('pcf_hip_knn_inverse_batched_workspace_bytes', [_I, _IP, _IP, _IP], _Z)
+_inv_batch = _sig('pcf_hip_knn_inverse_batched', [_I, _PP, _PP, _PP, _PP, _IP, _IP, _IP, _P, _Z, _P])
 _gridsub_ws = _sig('pcf_hip_grid_subsample_workspace_bytes', [_I, _I], _Z)
 _gridsub = _sig('pcf_hip_grid_subsample', [_P, _P, _P, _I, _I, _I, ctypes.c_float, _P, _P, _P, _P, _P, _Z, _P])
 _knn_grid = _sig('pcf_hip_knn_grid', [_P] * 4 + [_I] * 4 + [_P, _P, _Z, _P])
@@ -393,6 +397,47 @@ def compute_knn_inverse(neighbor_inds, total_points):
         _call(_inv, _ptr(neighbor_inds), _ptr(inv_neighbors), _ptr(inv_k), inv_idx.data_ptr(), ws.data_ptr(), nbytes,
               B, Nq, K, total_points, _stream(dev))
     return [inv_neighbors, inv_k, inv_idx]
+
+
+def compute_knn_inverse_batched(neighbor_inds_list, total_points_list):
+    """compute_knn_inverse for several neighbour tables at once: every phase of the transpose runs ONE launch over all
+    tables (the training loop transposes 3 x levels tables per iteration, util/common_util.py:281-309).  Tables are
+    [1, Nq, K] int64 on one device; returns a list of [inv_neighbors, inv_k, inv_idx] with the contents and shapes
+    compute_knn_inverse gives for each.  Empty tables take the single-table path."""
+    tables = list(neighbor_inds_list)
+    totals = [int(t) for t in total_points_list]
+    if len(tables) != len(totals):
+        raise RuntimeError('pcf_cuda: compute_knn_inverse_batched needs one total_points per table')
+    out = [None] * len(tables)
+    live = []
+    for i, (t, tp) in enumerate(zip(tables, totals)):
+        _check_input(t, 'neighbor_inds', torch.int64)
+        if t.dim() != 3:
+            raise RuntimeError('pcf_cuda: neighbor_inds must be [B,N,K]')
+        if t.shape[0] != 1 or t.shape[1] == 0 or tp == 0:
+            out[i] = compute_knn_inverse(t, tp)
+        else:
+            live.append(i)
+    if not live:
+        return out
+    dev = _same_device(*[tables[i] for i in live])
+    n = len(live)
+    Nq = (ctypes.c_int * n)(*[tables[i].shape[1] for i in live])
+    K = (ctypes.c_int * n)(*[tables[i].shape[2] for i in live])
+    TP = (ctypes.c_int * n)(*[totals[i] for i in live])
+    idx_p, n_p, k_p, x_p = ((ctypes.c_void_p * n)() for _ in range(4))
+    for j, i in enumerate(live):
+        t = tables[i]
+        e = t.shape[1] * t.shape[2]
+        trio = [torch.empty(1, e, dtype=torch.int32, device=dev), torch.empty(1, e, dtype=torch.uint8, device=dev),
+                torch.empty(1, totals[i] + 1, dtype=torch.int32, device=dev)]
+        out[i] = trio
+        idx_p[j], n_p[j], k_p[j], x_p[j] = t.data_ptr(), trio[0].data_ptr(), trio[1].data_ptr(), trio[2].data_ptr()
+    nbytes = _inv_batch_ws(n, Nq, K, TP)
+    ws = _workspace(nbytes, dev)
+    with _guard(dev):
+        _call(_inv_batch, n, idx_p, n_p, k_p, x_p, Nq, K, TP, ws.data_ptr(), nbytes, _stream(dev))
+    return out
 
 
 # ---- extras beyond the reference's nine (used by knn_post_dataloader_utils and the tests) --------

@@ -258,6 +258,35 @@ def test_knn_inverse_one_huge_bucket(device):
     np.testing.assert_array_equal(inv_k[0].cpu().numpy(), wk)
 
 
+def test_knn_inverse_batched_equals_oracle(device):
+    """All tables of an iteration in one pass of launches (pcf_hip_knn_inverse_batched): 19 tables (two launch groups of
+    16 + 3) of very different sizes -- small K, K = 255, mean in-degree > 64 (LDS sort), one bucket holding every edge
+    (rank-by-counting), out-of-range indices, a single edge, and an empty table that takes the single-table path -- each
+    bit-identical to the oracle."""
+    import pcf_cuda
+    rng = np.random.default_rng(11)
+    shapes = [(500, 16, 500), (300, 8, 1000), (2000, 16, 150), (77, 255, 9), (1, 1, 1), (4000, 16, 4000), (900, 12, 3000)]
+    shapes += [(int(rng.integers(5, 600)), int(rng.integers(1, 20)), int(rng.integers(1, 900))) for _ in range(10)]
+    tables, totals = [], []
+    for Nq, K, total in shapes:
+        idx = rng.integers(0, total, (Nq, K)).astype(np.int64)
+        idx[rng.random((Nq, K)) < 0.05] = -1
+        idx[rng.random((Nq, K)) < 0.02] = total + 5
+        tables.append(idx)
+        totals.append(total)
+    tables.append(np.full((500, 16), 3, np.int64)); totals.append(10)          # one bucket with 8000 entries
+    tables.append(np.zeros((0, 16), np.int64)); totals.append(7)                # empty table
+    got = pcf_cuda.compute_knn_inverse_batched([torch.from_numpy(t)[None].to(device) for t in tables], totals)
+    assert len(got) == len(tables)
+    for (inv_n, inv_k, inv_idx), idx, total in zip(got, tables, totals):
+        wn, wk, wi = O.knn_inverse(idx, total)
+        assert inv_n.shape == (1, idx.size) and inv_k.shape == (1, idx.size) and inv_idx.shape == (1, total + 1)
+        assert inv_n.dtype == torch.int32 and inv_k.dtype == torch.uint8 and inv_idx.dtype == torch.int32
+        np.testing.assert_array_equal(inv_idx[0].cpu().numpy(), wi)
+        np.testing.assert_array_equal(inv_n[0].cpu().numpy(), wn)
+        np.testing.assert_array_equal(inv_k[0].cpu().numpy(), wk)
+
+
 @pytest.mark.parametrize('K', [1, 5, 16, 24, 40])
 def test_knn_bit_exact_small(device, K):
     import pcf_cuda
