@@ -76,9 +76,31 @@ def compute_knn(ref_points, query_points, K, dilated_rate=1, method='hip'):
     return idx[:, ::dilated_rate].contiguous() if dilated_rate > 1 else idx
 
 
-class _PackedEdges(list):
-    """The reference's nested list [sample][level] -> [n,K] local indices, plus the packed result."""
-    packed = None      # list over levels of int64 [sum_n, K] global (packed) indices
+class _PackedEdges:
+    """The reference's nested list [sample][level] -> [n,K] LOCAL index tensors, built only when somebody looks at it
+    (4 samples x 13 tables = 52 slice-and-subtract kernels per iteration that `prepare` never needs), plus the packed
+    result it is derived from."""
+
+    def __init__(self, packed, slices):
+        self.packed = packed      # list over levels of int64 [sum_n, K] global (packed) indices
+        self._slices = slices     # per level: list over samples of (query begin, query end, reference offset)
+        self._rows = None
+
+    def _materialise(self):
+        if self._rows is None:
+            n_samples = len(self._slices[0]) if self._slices else 0
+            self._rows = [[t[q0:q1] - r0 for t, per in zip(self.packed, self._slices) for (q0, q1, r0) in [per[s]]]
+                          for s in range(n_samples)]
+        return self._rows
+
+    def __len__(self):
+        return len(self._materialise())
+
+    def __getitem__(self, i):
+        return self._materialise()[i]
+
+    def __iter__(self):
+        return iter(self._materialise())
 
 
 def compute_knn_packed(pointclouds, points_stored, K_self, K_forward, K_propagate):
@@ -111,13 +133,11 @@ def compute_knn_packed(pointclouds, points_stored, K_self, K_forward, K_propagat
     packed_prop = [run(j, j - 1, K_propagate[j]) for j in range(1, L)]     # ref = level j,   query = level j-1
 
     def split(packed, ref_levels, qry_levels):
-        out = _PackedEdges([[] for _ in range(S)])
-        out.packed = packed
-        for t, (rl, ql) in zip(packed, zip(ref_levels, qry_levels)):
+        slices = []
+        for rl, ql in zip(ref_levels, qry_levels):
             roff, qoff = offs[rl][0], offs[ql][0]
-            for s in range(S):
-                out[s].append(t[qoff[s]:qoff[s + 1]] - int(roff[s]))
-        return out
+            slices.append([(int(qoff[s]), int(qoff[s + 1]), int(roff[s])) for s in range(S)])
+        return _PackedEdges(packed, slices)
 
     levels = list(range(L))
     return (split(packed_self, levels, levels), split(packed_fwd, levels[:-1], levels[1:]),
