@@ -435,15 +435,15 @@ def main():
     if rank == 0:
         Ci = C_FEAT // 4
         fwd_b, bwd_b = _agg_bytes(Ci, C_MID, HEADS, K_NEI)
-        cand = {'pcf_hip_pcf_forward': (fwd_b, 'agg_fwd_kernel<16,true,true>'),
-                'pcf_hip_pcf_backward': (bwd_b, 'agg_bwd_kernel<16,true,true,true>'),
+        cand = {'pcf_hip_pcf_forward': (fwd_b, 'agg_fwd_fx_mfma_kernel'),
+                'pcf_hip_pcf_backward': (bwd_b, 'agg_bwd_fx_mfma_kernel'),
                 'pcf_hip_pcf_backward_csr': (bwd_b, 'agg_bwd_kernel<16,true,false,true> + csr_reduce_kernel')}
         dom = max((k for k in cand if k in hip_ms), key=lambda k: hip_ms[k])
         bytes_per_launch = cand[dom][0] * n
         achieved = bytes_per_launch / (hip_ms[dom] * 1e-3) / 1e9
-        traffic = None     # HBM bytes per launch from the PMC counters (profiles/r01_pmc_traffic.json), same shape only
+        traffic = None     # HBM bytes per launch from the PMC counters (profiles/r01h_pmc_traffic.json), same shape only
         try:
-            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01h_pmc_traffic.json')))
             if pmc['shape'] == {'N': n, 'K': K_NEI, 'Ci': Ci, 'Cm': C_MID, 'H': HEADS}:
                 traffic = pmc['kernels'].get(cand[dom][1], {}).get('traffic_bytes')
         except (OSError, ValueError, KeyError):

@@ -14,6 +14,7 @@
 // layout.  grad_x is either float-atomic scatter-add (no CSR available) or a plain
 // store of every edge's contribution row for the CSR gather-reduce in csr_reduce_kernel.
 #include <algorithm>
+#include <cstdlib>
 
 #include "pcf_common.h"
 
@@ -327,6 +328,130 @@ __global__ __launch_bounds__(BLOCK) void agg_bwd_kernel(const AggArgs a) {
                 a.gguid[(n * K) * H + it] = acc;
             }
         }
+    }
+}
+
+// ---- BASELINE shape (K = 16, Ci = 16, Cm = 16, H = 8, guided) backward on the matrix cores ---------------------------
+// The LDS kernel above is bound by its own instruction streams at this shape (SQ counters: 46 us of VALU + 51 us of
+// LDS for 80k points, not HBM): per point it runs two 16x16x16 contractions as 128 wave-wide FMAs fed from LDS.  They
+// are exactly two v_mfma_f32_16x16x4_f32 chains (4 instructions each, exact fp32 products):
+//   dT[k][c] = sum_m w[k][m] * gout[c][m]        A = w row k, B = gout row c: both operands are 16-byte loads of
+//                                                row-major rows with the contraction step s covering m = 4q + s
+//   gw[k][m] = sum_c T[k][c] * gout[c][m]        A = x row k (gathered, 16 B per lane) * guidance, B = gout column
+// with q = lane >> 4; the accumulator leaves lane (lo = lane & 15, q) holding rows k = 4q..4q+3 of column lo, which
+// is the layout the row-contiguous scatter (64-byte segments per k), grad_guid (pairs c, c+8 one DPP apart) and the
+// grad_w stores want.  No LDS, no barriers: one wave per point, ~20 independent loads in flight.
+// 4x4 transpose between the four registers of a lane and the four lanes of its quad (two DPP exchange stages):
+// afterwards lane b holds in v[r] what lane r of the quad held in v[b].
+template <int CTRL>
+__device__ __forceinline__ float dpp_quad(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ void quad_transpose(float (&v)[4], int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2;
+#pragma unroll
+    for (int r = 0; r < 4; r += 2) {                  // partner lane ^ 1: quad_perm [1,0,3,2]
+        const float recv = dpp_quad<0xb1>(b0 ? v[r] : v[r + 1]);
+        if (b0) v[r] = recv; else v[r + 1] = recv;
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {                     // partner lane ^ 2: quad_perm [2,3,0,1]
+        const float recv = dpp_quad<0x4e>(b1 ? v[r] : v[r + 2]);
+        if (b1) v[r] = recv; else v[r + 2] = recv;
+    }
+}
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(BLOCK) void agg_bwd_fx_mfma_kernel(const AggArgs a) {
+    const int lane = lane_id();
+    const int lo = lane & 15, q = lane >> 4;
+    for (int n = blockIdx.x * NWAVE + wave_id(); n < a.total; n += gridDim.x * NWAVE) {
+        const int b = n / a.Nout;
+        const size_t e0 = (size_t)n * 16;                        // first edge of the point
+        const int64_t j = a.idx[e0 + lo];
+        const int rowl = (j >= 0 && j < a.N) ? (int)((int64_t)b * a.N + j) : -1;       // neighbour row of k = lo
+        const float* go = a.gout + (size_t)n * 256;
+        // operands of both products; everything is issued before the first use
+        const float4 w4 = ld4(a.w + (e0 + lo) * 16 + 4 * q);                          // w[k = lo][m = 4q + s]
+        const float4 go4 = ld4(go + lo * 16 + 4 * q);                                 // gout[c = lo][m = 4q + s]
+        const float4 g4 = ld4(a.guid + (e0 + lo) * 8 + 4 * (q & 1));                  // guid[k = lo][(4q + s) % 8]
+        float4 x4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rowl >= 0) x4 = ld4(a.x + (size_t)rowl * 16 + 4 * q);                     // x[k = lo][c = 4q + s]
+        // the same three tiles in the accumulator's layout (rows k = 4q + r of column lo): 16-byte loads of row pieces
+        // (lane (4a + b, q): row 4q + b, columns 4a..4a+3 -- a contiguous KiB per instruction for gout) turned by the
+        // quad transpose; four scalar loads of 64-byte pieces each were slower
+        const int kb = 4 * q + (lane & 3);
+        const int rowb = __shfl(rowl, kb, WAVE);
+        const float4 goT = ld4(go + kb * 16 + (lo & ~3));                                // gout[c = 4q + b][m = 4a..]
+        const float4 gsT = ld4(a.guid + (e0 + kb) * 8 + (lo & 4));                       // guid[k = 4q + b][4(a & 1)..]
+        float4 xT = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rowb >= 0) xT = ld4(a.x + (size_t)rowb * 16 + (lo & ~3));                   // x[k = 4q + b][c = 4a..]
+        int rowk[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rowk[r] = __shfl(rowl, 4 * q + r, WAVE);             // neighbour row of k = 4q + r
+        float gB[4] = {goT.x, goT.y, goT.z, goT.w};                                      // -> gout[c = 4q + r][m = lo]
+        float gs[4] = {gsT.x, gsT.y, gsT.z, gsT.w};                                      // -> guid[k = 4q + r][lo % 8]
+        float xs[4] = {xT.x, xT.y, xT.z, xT.w};                                          // -> x[k = 4q + r][c = lo]
+        quad_transpose(gB, lane);
+        quad_transpose(gs, lane);
+        quad_transpose(xs, lane);
+
+        v4f dT = {0.f, 0.f, 0.f, 0.f};                                                // dT[k = 4q + r][c = lo]
+        dT = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.x, go4.x, dT, 0, 0, 0);
+        dT = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.y, go4.y, dT, 0, 0, 0);
+        dT = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.z, go4.z, dT, 0, 0, 0);
+        dT = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.w, go4.w, dT, 0, 0, 0);
+        v4f gw = {0.f, 0.f, 0.f, 0.f};                                                // grad_w[k = 4q + r][m = lo]
+        gw = __builtin_amdgcn_mfma_f32_16x16x4f32(x4.x * g4.x, gB[0], gw, 0, 0, 0);
+        gw = __builtin_amdgcn_mfma_f32_16x16x4f32(x4.y * g4.y, gB[1], gw, 0, 0, 0);
+        gw = __builtin_amdgcn_mfma_f32_16x16x4f32(x4.z * g4.z, gB[2], gw, 0, 0, 0);
+        gw = __builtin_amdgcn_mfma_f32_16x16x4f32(x4.w * g4.w, gB[3], gw, 0, 0, 0);
+        float pr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (rowk[r] >= 0) atomicAdd(a.gx + (size_t)rowk[r] * 16 + lo, dT[r] * gs[r]);
+            pr[r] = dT[r] * xs[r];                                                    // grad_guid[k][h] = sum over c % 8 == h
+            pr[r] += __shfl_xor(pr[r], 8, WAVE);
+        }
+        // stores: a 4x4 transpose inside every quad of lanes turns "4 rows x one column" into "one row x 4 columns",
+        // so grad_w leaves as ONE 16-byte store per lane covering the point's contiguous KiB (four stores of 64-byte
+        // pieces ran at 3.7 TB/s) and grad_guid as one per lane of the lower half-rows (512 contiguous bytes)
+        float gwr[4] = {gw[0], gw[1], gw[2], gw[3]};
+        quad_transpose(gwr, lane);
+        quad_transpose(pr, lane);
+        const size_t e = e0 + 4 * q + (lane & 3);
+        st4(a.gw + e * 16 + (lo & ~3), make_float4(gwr[0], gwr[1], gwr[2], gwr[3]));
+        if (lo < 8) st4(a.gguid + e * 8 + (lo & ~3), make_float4(pr[0], pr[1], pr[2], pr[3]));
+    }
+}
+
+// Forward at the same shape: out[c][m] = sum_k T[k][c] * w[k][m], T = x[idx[k]][c] * guid[k][c % 8].  A (lane (c = lo, q),
+// step s <-> k = 4q + s) and B (w[k = 4q + s][m = lo]) are both "rows 4q..4q+3 of column lo": 16-byte loads of row
+// pieces + the quad transpose; the accumulator (rows c = 4q + r of column m) goes back through the transpose and
+// leaves as one 16-byte store per lane = the point's contiguous KiB.
+__global__ __launch_bounds__(BLOCK) void agg_fwd_fx_mfma_kernel(const AggArgs a) {
+    const int lane = lane_id();
+    const int lo = lane & 15, q = lane >> 4;
+    for (int n = blockIdx.x * NWAVE + wave_id(); n < a.total; n += gridDim.x * NWAVE) {
+        const int b = n / a.Nout;
+        const size_t e0 = (size_t)n * 16;
+        const int kb = 4 * q + (lane & 3);
+        const int64_t j = a.idx[e0 + kb];
+        const int rowb = (j >= 0 && j < a.N) ? (int)((int64_t)b * a.N + j) : -1;
+        const float4 wT = ld4(a.w + (e0 + kb) * 16 + (lo & ~3));                         // w[k = 4q + b][m = 4a..]
+        const float4 gsT = ld4(a.guid + (e0 + kb) * 8 + (lo & 4));                       // guid[k = 4q + b][4(a & 1)..]
+        float4 xT = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rowb >= 0) xT = ld4(a.x + (size_t)rowb * 16 + (lo & ~3));                   // x[k = 4q + b][c = 4a..]
+        float t[4] = {xT.x * gsT.x, xT.y * gsT.y, xT.z * gsT.z, xT.w * gsT.w};           // T[k = 4q + b][c = 4a..] (c % 8 = 4(a & 1)..)
+        float wB[4] = {wT.x, wT.y, wT.z, wT.w};
+        quad_transpose(t, lane);                                                         // -> T[k = 4q + r][c = lo]
+        quad_transpose(wB, lane);                                                        // -> w[k = 4q + r][m = lo]
+        v4f acc = {0.f, 0.f, 0.f, 0.f};                                                  // out[c = 4q + r][m = lo]
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(t[s2], wB[s2], acc, 0, 0, 0);
+        float o[4] = {acc[0], acc[1], acc[2], acc[3]};
+        quad_transpose(o, lane);                                                         // -> out[c = 4q + b][m = 4a..]
+        st4(a.out + (size_t)n * 256 + kb * 16 + (lo & ~3), make_float4(o[0], o[1], o[2], o[3]));
     }
 }
 
@@ -647,10 +772,21 @@ static int launch(KernelT kernel, const AggArgs& a, const Plan& pl, hipStream_t 
     return check_launch(what);
 }
 
+// PCF_AGG_LDS=1 keeps the LDS kernels for the BASELINE shape (the cross-check of the matrix-core ones)
+static bool agg_lds_only() {
+    static const bool v = [] { const char* e = getenv("PCF_AGG_LDS"); return e && e[0] == '1'; }();
+    return v;
+}
+
 static int launch_fwd(const AggArgs& a, const Plan& pl, hipStream_t s) {
 #define PCF_FWD(CMV)                                                                   \
     return pl.vrow ? launch(agg_fwd_kernel<CMV, true>, a, pl, s, "aggregate forward")  \
                    : launch(agg_fwd_kernel<CMV, false>, a, pl, s, "aggregate forward")
+    if (pl.fixed_shape && !agg_lds_only()) {
+        const int grid = (int)std::min<long long>(ceil_div(a.total, NWAVE), 256 * 64);
+        hipLaunchKernelGGL(agg_fwd_fx_mfma_kernel, dim3(grid), dim3(BLOCK), 0, s, a);
+        return check_launch("aggregate forward (matrix cores)");
+    }
     if (pl.fixed_shape) return launch(agg_fwd_kernel<16, true, true>, a, pl, s, "aggregate forward");
     switch (pl.cm_t) {
         case 1: PCF_FWD(1);
@@ -668,6 +804,11 @@ static int launch_bwd_mode(const AggArgs& a, const Plan& pl, hipStream_t s) {
 #define PCF_BWD(CMV)                                                                            \
     return pl.vrow ? launch(agg_bwd_kernel<CMV, true, ATOMIC>, a, pl, s, "aggregate backward")  \
                    : launch(agg_bwd_kernel<CMV, false, ATOMIC>, a, pl, s, "aggregate backward")
+    if (pl.fixed_shape && ATOMIC && !agg_lds_only()) {
+        const int grid = (int)std::min<long long>(ceil_div(a.total, NWAVE), 256 * 64);
+        hipLaunchKernelGGL(agg_bwd_fx_mfma_kernel, dim3(grid), dim3(BLOCK), 0, s, a);
+        return check_launch("aggregate backward (matrix cores)");
+    }
     if (pl.fixed_shape) return launch(agg_bwd_kernel<16, true, ATOMIC, true>, a, pl, s, "aggregate backward");
     switch (pl.cm_t) {
         case 1: PCF_BWD(1);
