@@ -46,6 +46,10 @@ PCF_SHAPES = [
     (1, 130, 130, 16, 48, 8, 8),
     (1, 90, 90, 16, 64, 32, 1),
     (1, 33, 77, 3, 7, 1, 7),           # Cm=1, odd Ci
+    (1, 400, 150, 16, 32, 4, 8),       # 10cm-lite PCFLayers (C_mid = 4): matrix-core kernels, strided
+    (2, 90, 90, 16, 64, 4, 8),         # ... batch 2, four channel tiles
+    (1, 150, 150, 16, 48, 4, 8),       # ... three channel tiles
+    (2, 120, 70, 16, 32, 16, 8),       # C_mid = 16, two channel tiles, batch 2, strided
 ]
 
 
