@@ -435,8 +435,8 @@ def main():
     if rank == 0:
         Ci = C_FEAT // 4
         fwd_b, bwd_b = _agg_bytes(Ci, C_MID, HEADS, K_NEI)
-        cand = {'pcf_hip_pcf_forward': (fwd_b, 'agg_fwd_mfma_kernel<16>'),
-                'pcf_hip_pcf_backward': (bwd_b, 'agg_bwd_mfma_kernel<16>'),
+        cand = {'pcf_hip_pcf_forward': (fwd_b, 'agg_fwd_fx_mfma_kernel'),
+                'pcf_hip_pcf_backward': (bwd_b, 'agg_bwd_fx_mfma_kernel'),
                 'pcf_hip_pcf_backward_csr': (bwd_b, 'agg_bwd_kernel<16,true,false,true> + csr_reduce_kernel')}
         dom = max((k for k in cand if k in hip_ms), key=lambda k: hip_ms[k])
         bytes_per_launch = cand[dom][0] * n

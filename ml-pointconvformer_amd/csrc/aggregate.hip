@@ -368,11 +368,12 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // 16-channel tiles) and C_mid = 16 (PCFLayers of the BASELINE configs: Ci 16..96) or C_mid = 4 (the 10cm-lite model).
 // For C_mid = 4 a w / gout / out row is one 16-byte quad: product 1 is ONE matrix instruction (contraction length 4),
 // and the 4-column operands / results live in lanes lo < 4 of every 16-lane row.
-template <int CM>
+// CI: compile-time channel count (the BASELINE shape: one tile, no loop, constant strides) or 0 = a.Ci at run time.
+template <int CM, int CI>
 __global__ __launch_bounds__(BLOCK) void agg_bwd_mfma_kernel(const AggArgs a) {
     const int lane = lane_id();
     const int lo = lane & 15, q = lane >> 4;
-    const int Ci = a.Ci, ntile = Ci >> 4;
+    const int Ci = CI ? CI : a.Ci, ntile = Ci >> 4;
     for (int n = blockIdx.x * NWAVE + wave_id(); n < a.total; n += gridDim.x * NWAVE) {
         const int b = n / a.Nout;
         const size_t e0 = (size_t)n * 16;                        // first edge of the point
@@ -443,11 +444,11 @@ __global__ __launch_bounds__(BLOCK) void agg_bwd_mfma_kernel(const AggArgs a) {
 // step s <-> k = 4q + s) and B (w[k = 4q + s][m = lo]) are both "rows 4q..4q+3 of column lo": 16-byte loads of row
 // pieces + the quad transpose; the accumulator (rows c = 4q + r of column m) goes back through the transpose and
 // leaves as one 16-byte store per lane = the tile's contiguous rows.
-template <int CM>
+template <int CM, int CI>
 __global__ __launch_bounds__(BLOCK) void agg_fwd_mfma_kernel(const AggArgs a) {
     const int lane = lane_id();
     const int lo = lane & 15, q = lane >> 4;
-    const int Ci = a.Ci, ntile = Ci >> 4;
+    const int Ci = CI ? CI : a.Ci, ntile = Ci >> 4;
     for (int n = blockIdx.x * NWAVE + wave_id(); n < a.total; n += gridDim.x * NWAVE) {
         const int b = n / a.Nout;
         const size_t e0 = (size_t)n * 16;
@@ -476,6 +477,101 @@ __global__ __launch_bounds__(BLOCK) void agg_fwd_mfma_kernel(const AggArgs a) {
             if (CM == 16) st4(out + (size_t)(c0 + kb) * 16 + (lo & ~3), ov);
             else if (lo < 4) st4(out + (size_t)(c0 + kb) * 4, ov);
         }
+    }
+}
+
+// The BASELINE shape (Ci = Cm = 16) written out without the tile loop: every load of a point is issued before the first
+// use (measured 89 us against 96 us for the tiled form instantiated at Ci = 16, 80k points).
+__global__ __launch_bounds__(BLOCK) void agg_bwd_fx_mfma_kernel(const AggArgs a) {
+    const int lane = lane_id();
+    const int lo = lane & 15, q = lane >> 4;
+    for (int n = blockIdx.x * NWAVE + wave_id(); n < a.total; n += gridDim.x * NWAVE) {
+        const int b = n / a.Nout;
+        const size_t e0 = (size_t)n * 16;                        // first edge of the point
+        const int64_t j = a.idx[e0 + lo];
+        const int rowl = (j >= 0 && j < a.N) ? (int)((int64_t)b * a.N + j) : -1;       // neighbour row of k = lo
+        const float* go = a.gout + (size_t)n * 256;
+        // operands of both products; everything is issued before the first use
+        const float4 w4 = ld4(a.w + (e0 + lo) * 16 + 4 * q);                          // w[k = lo][m = 4q + s]
+        const float4 go4 = ld4(go + lo * 16 + 4 * q);                                 // gout[c = lo][m = 4q + s]
+        const float4 g4 = ld4(a.guid + (e0 + lo) * 8 + 4 * (q & 1));                  // guid[k = lo][(4q + s) % 8]
+        float4 x4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rowl >= 0) x4 = ld4(a.x + (size_t)rowl * 16 + 4 * q);                     // x[k = lo][c = 4q + s]
+        // the same three tiles in the accumulator's layout (rows k = 4q + r of column lo): 16-byte loads of row pieces
+        // (lane (4a + b, q): row 4q + b, columns 4a..4a+3 -- a contiguous KiB per instruction for gout) turned by the
+        // quad transpose; four scalar loads of 64-byte pieces each were slower
+        const int kb = 4 * q + (lane & 3);
+        const int rowb = __shfl(rowl, kb, WAVE);
+        const float4 goT = ld4(go + kb * 16 + (lo & ~3));                                // gout[c = 4q + b][m = 4a..]
+        const float4 gsT = ld4(a.guid + (e0 + kb) * 8 + (lo & 4));                       // guid[k = 4q + b][4(a & 1)..]
+        float4 xT = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rowb >= 0) xT = ld4(a.x + (size_t)rowb * 16 + (lo & ~3));                   // x[k = 4q + b][c = 4a..]
+        int rowk[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rowk[r] = __shfl(rowl, 4 * q + r, WAVE);             // neighbour row of k = 4q + r
+        float gB[4] = {goT.x, goT.y, goT.z, goT.w};                                      // -> gout[c = 4q + r][m = lo]
+        float gs[4] = {gsT.x, gsT.y, gsT.z, gsT.w};                                      // -> guid[k = 4q + r][lo % 8]
+        float xs[4] = {xT.x, xT.y, xT.z, xT.w};                                          // -> x[k = 4q + r][c = lo]
+        quad_transpose(gB, lane);
+        quad_transpose(gs, lane);
+        quad_transpose(xs, lane);
+
+        v4f dT = {0.f, 0.f, 0.f, 0.f};                                                // dT[k = 4q + r][c = lo]
+        dT = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.x, go4.x, dT, 0, 0, 0);
+        dT = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.y, go4.y, dT, 0, 0, 0);
+        dT = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.z, go4.z, dT, 0, 0, 0);
+        dT = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.w, go4.w, dT, 0, 0, 0);
+        v4f gw = {0.f, 0.f, 0.f, 0.f};                                                // grad_w[k = 4q + r][m = lo]
+        gw = __builtin_amdgcn_mfma_f32_16x16x4f32(x4.x * g4.x, gB[0], gw, 0, 0, 0);
+        gw = __builtin_amdgcn_mfma_f32_16x16x4f32(x4.y * g4.y, gB[1], gw, 0, 0, 0);
+        gw = __builtin_amdgcn_mfma_f32_16x16x4f32(x4.z * g4.z, gB[2], gw, 0, 0, 0);
+        gw = __builtin_amdgcn_mfma_f32_16x16x4f32(x4.w * g4.w, gB[3], gw, 0, 0, 0);
+        float pr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (rowk[r] >= 0) atomicAdd(a.gx + (size_t)rowk[r] * 16 + lo, dT[r] * gs[r]);
+            pr[r] = dT[r] * xs[r];                                                    // grad_guid[k][h] = sum over c % 8 == h
+            pr[r] += __shfl_xor(pr[r], 8, WAVE);
+        }
+        // stores: a 4x4 transpose inside every quad of lanes turns "4 rows x one column" into "one row x 4 columns",
+        // so grad_w leaves as ONE 16-byte store per lane covering the point's contiguous KiB (four stores of 64-byte
+        // pieces ran at 3.7 TB/s) and grad_guid as one per lane of the lower half-rows (512 contiguous bytes)
+        float gwr[4] = {gw[0], gw[1], gw[2], gw[3]};
+        quad_transpose(gwr, lane);
+        quad_transpose(pr, lane);
+        const size_t e = e0 + 4 * q + (lane & 3);
+        st4(a.gw + e * 16 + (lo & ~3), make_float4(gwr[0], gwr[1], gwr[2], gwr[3]));
+        if (lo < 8) st4(a.gguid + e * 8 + (lo & ~3), make_float4(pr[0], pr[1], pr[2], pr[3]));
+    }
+}
+
+// Forward at the same shape: out[c][m] = sum_k T[k][c] * w[k][m], T = x[idx[k]][c] * guid[k][c % 8].  A (lane (c = lo, q),
+// step s <-> k = 4q + s) and B (w[k = 4q + s][m = lo]) are both "rows 4q..4q+3 of column lo": 16-byte loads of row
+// pieces + the quad transpose; the accumulator (rows c = 4q + r of column m) goes back through the transpose and
+// leaves as one 16-byte store per lane = the point's contiguous KiB.
+__global__ __launch_bounds__(BLOCK) void agg_fwd_fx_mfma_kernel(const AggArgs a) {
+    const int lane = lane_id();
+    const int lo = lane & 15, q = lane >> 4;
+    for (int n = blockIdx.x * NWAVE + wave_id(); n < a.total; n += gridDim.x * NWAVE) {
+        const int b = n / a.Nout;
+        const size_t e0 = (size_t)n * 16;
+        const int kb = 4 * q + (lane & 3);
+        const int64_t j = a.idx[e0 + kb];
+        const int rowb = (j >= 0 && j < a.N) ? (int)((int64_t)b * a.N + j) : -1;
+        const float4 wT = ld4(a.w + (e0 + kb) * 16 + (lo & ~3));                         // w[k = 4q + b][m = 4a..]
+        const float4 gsT = ld4(a.guid + (e0 + kb) * 8 + (lo & 4));                       // guid[k = 4q + b][4(a & 1)..]
+        float4 xT = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rowb >= 0) xT = ld4(a.x + (size_t)rowb * 16 + (lo & ~3));                   // x[k = 4q + b][c = 4a..]
+        float t[4] = {xT.x * gsT.x, xT.y * gsT.y, xT.z * gsT.z, xT.w * gsT.w};           // T[k = 4q + b][c = 4a..] (c % 8 = 4(a & 1)..)
+        float wB[4] = {wT.x, wT.y, wT.z, wT.w};
+        quad_transpose(t, lane);                                                         // -> T[k = 4q + r][c = lo]
+        quad_transpose(wB, lane);                                                        // -> w[k = 4q + r][m = lo]
+        v4f acc = {0.f, 0.f, 0.f, 0.f};                                                  // out[c = 4q + r][m = lo]
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(t[s2], wB[s2], acc, 0, 0, 0);
+        float o[4] = {acc[0], acc[1], acc[2], acc[3]};
+        quad_transpose(o, lane);                                                         // -> out[c = 4q + b][m = 4a..]
+        st4(a.out + (size_t)n * 256 + kb * 16 + (lo & ~3), make_float4(o[0], o[1], o[2], o[3]));
     }
 }
 
@@ -804,14 +900,21 @@ static bool agg_lds_only() {
     return v;
 }
 
+// PCF_AGG_TILED=1 runs the BASELINE shape through the tiled kernels (test hook)
+static bool agg_tiled_only() {
+    static const bool v = [] { const char* e = getenv("PCF_AGG_TILED"); return e && e[0] == '1'; }();
+    return v;
+}
+
 static int launch_fwd(const AggArgs& a, const Plan& pl, hipStream_t s) {
 #define PCF_FWD(CMV)                                                                   \
     return pl.vrow ? launch(agg_fwd_kernel<CMV, true>, a, pl, s, "aggregate forward")  \
                    : launch(agg_fwd_kernel<CMV, false>, a, pl, s, "aggregate forward")
     if (pl.mfma_shape && !agg_lds_only()) {
         const int grid = (int)std::min<long long>(ceil_div(a.total, NWAVE), 256 * 64);
-        if (a.Cm == 16) hipLaunchKernelGGL(agg_fwd_mfma_kernel<16>, dim3(grid), dim3(BLOCK), 0, s, a);
-        else hipLaunchKernelGGL(agg_fwd_mfma_kernel<4>, dim3(grid), dim3(BLOCK), 0, s, a);
+        if (a.Cm == 16 && a.Ci == 16 && !agg_tiled_only()) hipLaunchKernelGGL(agg_fwd_fx_mfma_kernel, dim3(grid), dim3(BLOCK), 0, s, a);
+        else if (a.Cm == 16) hipLaunchKernelGGL((agg_fwd_mfma_kernel<16, 0>), dim3(grid), dim3(BLOCK), 0, s, a);
+        else hipLaunchKernelGGL((agg_fwd_mfma_kernel<4, 0>), dim3(grid), dim3(BLOCK), 0, s, a);
         return check_launch("aggregate forward (matrix cores)");
     }
     if (pl.fixed_shape) return launch(agg_fwd_kernel<16, true, true>, a, pl, s, "aggregate forward");
@@ -833,8 +936,9 @@ static int launch_bwd_mode(const AggArgs& a, const Plan& pl, hipStream_t s) {
                    : launch(agg_bwd_kernel<CMV, false, ATOMIC>, a, pl, s, "aggregate backward")
     if (pl.mfma_shape && ATOMIC && !agg_lds_only()) {
         const int grid = (int)std::min<long long>(ceil_div(a.total, NWAVE), 256 * 64);
-        if (a.Cm == 16) hipLaunchKernelGGL(agg_bwd_mfma_kernel<16>, dim3(grid), dim3(BLOCK), 0, s, a);
-        else hipLaunchKernelGGL(agg_bwd_mfma_kernel<4>, dim3(grid), dim3(BLOCK), 0, s, a);
+        if (a.Cm == 16 && a.Ci == 16 && !agg_tiled_only()) hipLaunchKernelGGL(agg_bwd_fx_mfma_kernel, dim3(grid), dim3(BLOCK), 0, s, a);
+        else if (a.Cm == 16) hipLaunchKernelGGL((agg_bwd_mfma_kernel<16, 0>), dim3(grid), dim3(BLOCK), 0, s, a);
+        else hipLaunchKernelGGL((agg_bwd_mfma_kernel<4, 0>), dim3(grid), dim3(BLOCK), 0, s, a);
         return check_launch("aggregate backward (matrix cores)");
     }
     if (pl.fixed_shape) return launch(agg_bwd_kernel<16, true, ATOMIC, true>, a, pl, s, "aggregate backward");
