@@ -391,39 +391,47 @@ __global__ __launch_bounds__(BLOCK) void agg_bwd_mfma_kernel(const AggArgs a) {
         else w4.x = a.w[(e0 + lo) * 4 + q];                                              // w[k = lo][m = q]
         const float4 g4 = ld4(a.guid + (e0 + lo) * 8 + 4 * (q & 1));                     // guid[k = lo][(4q + s) % 8]
         const float4 gsT = ld4(a.guid + (e0 + kb) * 8 + (lo & 4));                       // guid[k = 4q + b][4(a & 1)..]
-        float gs[4] = {gsT.x, gsT.y, gsT.z, gsT.w};
-        quad_transpose(gs, lane);                                                        // -> guid[k = 4q + r][lo % 8]
         v4f gw = {0.f, 0.f, 0.f, 0.f};                                                   // grad_w[k = 4q + r][m = lo]
         float pr[4] = {0.f, 0.f, 0.f, 0.f};
+        // one 16-channel tile of operands: gout rows for product 1 (A side: row pieces m = 4q + s), and x / gout in the
+        // accumulator's layout as 16-byte row pieces for the quad transpose
+        struct Tile { float4 go4, xT, x4, goT; };
+        auto load_tile = [&](int c0, Tile& t) {
+            t.go4 = t.xT = t.x4 = t.goT = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (CM == 16) t.go4 = ld4(go + (size_t)(c0 + lo) * 16 + 4 * q);             // gout[c = c0 + lo][m = 4q + s]
+            else t.go4.x = go[(size_t)(c0 + lo) * 4 + q];                                // gout[c = c0 + lo][m = q]
+            if (rowb >= 0) t.xT = ld4(a.x + (size_t)rowb * Ci + c0 + (lo & ~3));         // x[k = 4q + b][c0 + 4a..]
+            if (rowl >= 0) t.x4 = ld4(a.x + (size_t)rowl * Ci + c0 + 4 * q);             // x[k = lo][c0 + 4q + s]
+            if (CM == 16) t.goT = ld4(go + (size_t)(c0 + kb) * 16 + (lo & ~3));          // gout[c0 + 4q + b][m = 4a..]
+            else if (lo < 4) t.goT = ld4(go + (size_t)(c0 + kb) * 4);                    // gout[c0 + 4q + b][m = 0..3]
+        };
+        Tile cur;
+        load_tile(0, cur);
+        float gs[4] = {gsT.x, gsT.y, gsT.z, gsT.w};
+        quad_transpose(gs, lane);                                                        // -> guid[k = 4q + r][lo % 8]
         for (int ct = 0; ct < ntile; ++ct) {
             const int c0 = 16 * ct;
+            Tile nxt = cur;
+            if (ct + 1 < ntile) load_tile(c0 + 16, nxt);          // the next tile's loads go out before this tile's atomics
             // product 1: dT[k = 4q + r][c = c0 + lo] = sum_m w[k][m] * gout[c][m]; both operands are row loads
             v4f dT = {0.f, 0.f, 0.f, 0.f};
+            dT = PCF_MFMA16(w4.x, cur.go4.x, dT);
             if (CM == 16) {
-                const float4 go4 = ld4(go + (size_t)(c0 + lo) * 16 + 4 * q);             // gout[c = c0 + lo][m = 4q + s]
-                dT = PCF_MFMA16(w4.x, go4.x, dT); dT = PCF_MFMA16(w4.y, go4.y, dT);
-                dT = PCF_MFMA16(w4.z, go4.z, dT); dT = PCF_MFMA16(w4.w, go4.w, dT);
-            } else {
-                dT = PCF_MFMA16(w4.x, go[(size_t)(c0 + lo) * 4 + q], dT);                // gout[c = c0 + lo][m = q]
+                dT = PCF_MFMA16(w4.y, cur.go4.y, dT); dT = PCF_MFMA16(w4.z, cur.go4.z, dT); dT = PCF_MFMA16(w4.w, cur.go4.w, dT);
             }
-            // tiles in the accumulator's layout (rows 4q + r of column lo): 16-byte row pieces + the quad transpose
-            float4 xT = make_float4(0.f, 0.f, 0.f, 0.f), x4 = xT, goT = xT;
-            if (rowb >= 0) xT = ld4(a.x + (size_t)rowb * Ci + c0 + (lo & ~3));           // x[k = 4q + b][c0 + 4a..]
-            if (rowl >= 0) x4 = ld4(a.x + (size_t)rowl * Ci + c0 + 4 * q);               // x[k = lo][c0 + 4q + s]
-            if (CM == 16) goT = ld4(go + (size_t)(c0 + kb) * 16 + (lo & ~3));            // gout[c0 + 4q + b][m = 4a..]
-            else if (lo < 4) goT = ld4(go + (size_t)(c0 + kb) * 4);                      // gout[c0 + 4q + b][m = 0..3]
-            float xs[4] = {xT.x, xT.y, xT.z, xT.w};
-            float gB[4] = {goT.x, goT.y, goT.z, goT.w};
+            float xs[4] = {cur.xT.x, cur.xT.y, cur.xT.z, cur.xT.w};
+            float gB[4] = {cur.goT.x, cur.goT.y, cur.goT.z, cur.goT.w};
             quad_transpose(xs, lane);                                                    // -> x[k = 4q + r][c = c0 + lo]
             quad_transpose(gB, lane);                                                    // -> gout[c0 + 4q + r][m = lo]
             // product 2: grad_w[k][m] += sum_c T[k][c] * gout[c][m], T = x * guid
-            gw = PCF_MFMA16(x4.x * g4.x, gB[0], gw); gw = PCF_MFMA16(x4.y * g4.y, gB[1], gw);
-            gw = PCF_MFMA16(x4.z * g4.z, gB[2], gw); gw = PCF_MFMA16(x4.w * g4.w, gB[3], gw);
+            gw = PCF_MFMA16(cur.x4.x * g4.x, gB[0], gw); gw = PCF_MFMA16(cur.x4.y * g4.y, gB[1], gw);
+            gw = PCF_MFMA16(cur.x4.z * g4.z, gB[2], gw); gw = PCF_MFMA16(cur.x4.w * g4.w, gB[3], gw);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (rowk[r] >= 0) atomicAdd(a.gx + (size_t)rowk[r] * Ci + c0 + lo, dT[r] * gs[r]);
                 pr[r] = fmaf(dT[r], xs[r], pr[r]);                                       // grad_guid[k][h]: sum over c % 8 == h
             }
+            cur = nxt;
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) pr[r] += __shfl_xor(pr[r], 8, WAVE);
