@@ -488,6 +488,102 @@ __global__ __launch_bounds__(BLOCK) void agg_fwd_mfma_kernel(const AggArgs a) {
     }
 }
 
+// Unguided form (PointConvStridePE of the BASELINE configs: Ci = 16 gathered + Ca = 16 appended channels, K = 16): the
+// same two kernels with T[k][c] = x[idx[k]][c] for c < Ci and add[n, k, c - Ci] behind it, walked in 16-channel tiles
+// (both widths multiples of 16).  Backward: gathered tiles of dT leave as float atomics (ATOMIC) or as the contribution
+// rows of the CSR reduce, appended tiles as grad_add -- both through the quad transpose as 16-byte stores.
+template <int CM>
+__global__ __launch_bounds__(BLOCK) void pconv_fwd_mfma_kernel(const AggArgs a) {
+    const int lane = lane_id();
+    const int lo = lane & 15, q = lane >> 4;
+    const int Ci = a.Ci, Ca = a.Ca, CT = Ci + Ca, ntile = CT >> 4;
+    for (int n = blockIdx.x * NWAVE + wave_id(); n < a.total; n += gridDim.x * NWAVE) {
+        const int b = n / a.Nout;
+        const size_t e0 = (size_t)n * 16;
+        const int kb = 4 * q + (lane & 3);
+        const int64_t j = a.idx[e0 + kb];
+        const int rowb = (j >= 0 && j < a.N) ? (int)((int64_t)b * a.N + j) : -1;
+        float4 wT = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (CM == 16) wT = ld4(a.w + (e0 + kb) * 16 + (lo & ~3));                        // w[k = 4q + b][m = 4a..]
+        else if (lo < 4) wT = ld4(a.w + (e0 + kb) * 4);                                  // w[k = 4q + b][m = 0..3]
+        float wB[4] = {wT.x, wT.y, wT.z, wT.w};
+        quad_transpose(wB, lane);                                                        // -> w[k = 4q + r][m = lo]
+        float* out = a.out + (size_t)n * CT * CM;
+        for (int ct = 0; ct < ntile; ++ct) {
+            const int c0 = 16 * ct;
+            float4 xT = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c0 < Ci) { if (rowb >= 0) xT = ld4(a.x + (size_t)rowb * Ci + c0 + (lo & ~3)); }     // x[k = 4q + b][c0 + 4a..]
+            else xT = ld4(a.add + (e0 + kb) * Ca + (c0 - Ci) + (lo & ~3));                            // add[k = 4q + b][..]
+            float t[4] = {xT.x, xT.y, xT.z, xT.w};
+            quad_transpose(t, lane);                                                     // -> T[k = 4q + r][c = c0 + lo]
+            v4f acc = {0.f, 0.f, 0.f, 0.f};                                              // out[c = c0 + 4q + r][m = lo]
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) acc = PCF_MFMA16(t[s2], wB[s2], acc);
+            float o[4] = {acc[0], acc[1], acc[2], acc[3]};
+            quad_transpose(o, lane);                                                     // -> out[c = c0 + 4q + b][m = 4a..]
+            const float4 ov = make_float4(o[0], o[1], o[2], o[3]);
+            if (CM == 16) st4(out + (size_t)(c0 + kb) * 16 + (lo & ~3), ov);
+            else if (lo < 4) st4(out + (size_t)(c0 + kb) * 4, ov);
+        }
+    }
+}
+
+template <int CM, bool ATOMIC>
+__global__ __launch_bounds__(BLOCK) void pconv_bwd_mfma_kernel(const AggArgs a) {
+    const int lane = lane_id();
+    const int lo = lane & 15, q = lane >> 4;
+    const int Ci = a.Ci, Ca = a.Ca, CT = Ci + Ca, ntile = CT >> 4;
+    for (int n = blockIdx.x * NWAVE + wave_id(); n < a.total; n += gridDim.x * NWAVE) {
+        const int b = n / a.Nout;
+        const size_t e0 = (size_t)n * 16;
+        const int64_t j = a.idx[e0 + lo];
+        const int rowl = (j >= 0 && j < a.N) ? (int)((int64_t)b * a.N + j) : -1;       // neighbour row of k = lo
+        const int kb = 4 * q + (lane & 3);
+        int rowk[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rowk[r] = __shfl(rowl, 4 * q + r, WAVE);             // ... of k = 4q + r
+        const float* go = a.gout + (size_t)n * CT * CM;
+        float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (CM == 16) w4 = ld4(a.w + (e0 + lo) * 16 + 4 * q);                           // w[k = lo][m = 4q + s]
+        else w4.x = a.w[(e0 + lo) * 4 + q];                                              // w[k = lo][m = q]
+        v4f gw = {0.f, 0.f, 0.f, 0.f};                                                   // grad_w[k = 4q + r][m = lo]
+        for (int ct = 0; ct < ntile; ++ct) {
+            const int c0 = 16 * ct;
+            const bool gathered = c0 < Ci;
+            float4 go4 = make_float4(0.f, 0.f, 0.f, 0.f), x4 = go4, goT = go4;
+            if (CM == 16) go4 = ld4(go + (size_t)(c0 + lo) * 16 + 4 * q);                // gout[c = c0 + lo][m = 4q + s]
+            else go4.x = go[(size_t)(c0 + lo) * 4 + q];                                  // gout[c = c0 + lo][m = q]
+            if (gathered) { if (rowl >= 0) x4 = ld4(a.x + (size_t)rowl * Ci + c0 + 4 * q); }         // T[k = lo][c0 + 4q + s]
+            else x4 = ld4(a.add + (e0 + lo) * Ca + (c0 - Ci) + 4 * q);
+            if (CM == 16) goT = ld4(go + (size_t)(c0 + kb) * 16 + (lo & ~3));            // gout[c0 + 4q + b][m = 4a..]
+            else if (lo < 4) goT = ld4(go + (size_t)(c0 + kb) * 4);                      // gout[c0 + 4q + b][m = 0..3]
+            v4f dT = {0.f, 0.f, 0.f, 0.f};                                               // dT[k = 4q + r][c = c0 + lo]
+            dT = PCF_MFMA16(w4.x, go4.x, dT);
+            if (CM == 16) { dT = PCF_MFMA16(w4.y, go4.y, dT); dT = PCF_MFMA16(w4.z, go4.z, dT); dT = PCF_MFMA16(w4.w, go4.w, dT); }
+            float gB[4] = {goT.x, goT.y, goT.z, goT.w};
+            quad_transpose(gB, lane);                                                    // -> gout[c0 + 4q + r][m = lo]
+            gw = PCF_MFMA16(x4.x, gB[0], gw); gw = PCF_MFMA16(x4.y, gB[1], gw);
+            gw = PCF_MFMA16(x4.z, gB[2], gw); gw = PCF_MFMA16(x4.w, gB[3], gw);
+            if (gathered && ATOMIC) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (rowk[r] >= 0) atomicAdd(a.gx + (size_t)rowk[r] * Ci + c0 + lo, dT[r]);
+            } else {
+                float d[4] = {dT[0], dT[1], dT[2], dT[3]};
+                quad_transpose(d, lane);                                                 // -> dT[k = 4q + b][c0 + 4a..]
+                const float4 dv = make_float4(d[0], d[1], d[2], d[3]);
+                if (gathered) st4(a.contrib + (e0 + kb) * Ci + c0 + (lo & ~3), dv);
+                else st4(a.gadd + (e0 + kb) * Ca + (c0 - Ci) + (lo & ~3), dv);
+            }
+        }
+        float gwr[4] = {gw[0], gw[1], gw[2], gw[3]};
+        quad_transpose(gwr, lane);
+        const float4 gwv = make_float4(gwr[0], gwr[1], gwr[2], gwr[3]);
+        if (CM == 16) st4(a.gw + (e0 + kb) * 16 + (lo & ~3), gwv);
+        else if (lo < 4) st4(a.gw + (e0 + kb) * 4, gwv);
+    }
+}
+
 // The BASELINE shape (Ci = Cm = 16) written out without the tile loop: every load of a point is issued before the first
 // use (measured 89 us against 96 us for the tiled form instantiated at Ci = 16, 80k points).
 __global__ __launch_bounds__(BLOCK) void agg_bwd_fx_mfma_kernel(const AggArgs a) {
@@ -833,6 +929,7 @@ struct Plan {
     bool vrow;
     bool fixed_shape;      // K = 16, Ci = 16, Ca = 0, H = 8, Cm = 16, guided, 16-byte rows
     bool mfma_shape;       // K = 16, H = 8, guided, Ca = 0, Ci % 16 == 0, Cm in {4, 16}, 16-byte rows: the matrix-core kernels
+    bool pconv_mfma_shape; // K = 16, unguided, Ci % 16 == 0, Ca % 16 == 0, Ci + Ca >= 16, Cm in {4, 16}, 16-byte rows
     int cm_t;   // template Cm (0 = run-time)
 };
 
@@ -857,6 +954,7 @@ static int make_plan(Plan& pl, bool backward, bool guided, int total, int K, int
     pl.fixed_shape = guided && pl.vrow && pl.cm_t == 16 && K == 16 && Ci == 16 && Ca == 0 && H == 8 &&
                      pl.TS == (backward ? 20 : 16) && pl.GS == 20;
     pl.mfma_shape = guided && pl.vrow && K == 16 && H == 8 && Ca == 0 && Ci >= 16 && Ci % 16 == 0 && (Cm == 16 || Cm == 4);
+    pl.pconv_mfma_shape = !guided && pl.vrow && K == 16 && Ci % 16 == 0 && Ca % 16 == 0 && Ci + Ca >= 16 && (Cm == 16 || Cm == 4);
     auto r4 = [](size_t v) { return (v + 3) / 4 * 4; };
     const size_t per_pt_idx = K;
     const size_t per_pt_g = guided ? (size_t)K * H : 0;
@@ -925,6 +1023,14 @@ static int launch_fwd(const AggArgs& a, const Plan& pl, hipStream_t s) {
         else hipLaunchKernelGGL((agg_fwd_mfma_kernel<4, 0>), dim3(grid), dim3(BLOCK), 0, s, a);
         return check_launch("aggregate forward (matrix cores)");
     }
+    // unguided forward: C_mid = 16 only (at C_mid = 4 the 64-byte output rows make the LDS kernel's coalesced stores
+    // the better deal: 69 vs 82 us at 144k points, Ci = Ca = 16); PCF_AGG_TILED=1 forces it (tests)
+    if (pl.pconv_mfma_shape && !agg_lds_only() && (a.Cm == 16 || agg_tiled_only())) {
+        const int grid = (int)std::min<long long>(ceil_div(a.total, NWAVE), 256 * 64);
+        if (a.Cm == 16) hipLaunchKernelGGL(pconv_fwd_mfma_kernel<16>, dim3(grid), dim3(BLOCK), 0, s, a);
+        else hipLaunchKernelGGL(pconv_fwd_mfma_kernel<4>, dim3(grid), dim3(BLOCK), 0, s, a);
+        return check_launch("aggregate forward (matrix cores, unguided)");
+    }
     if (pl.fixed_shape) return launch(agg_fwd_kernel<16, true, true>, a, pl, s, "aggregate forward");
     switch (pl.cm_t) {
         case 1: PCF_FWD(1);
@@ -948,6 +1054,12 @@ static int launch_bwd_mode(const AggArgs& a, const Plan& pl, hipStream_t s) {
         else if (a.Cm == 16) hipLaunchKernelGGL((agg_bwd_mfma_kernel<16, 0>), dim3(grid), dim3(BLOCK), 0, s, a);
         else hipLaunchKernelGGL((agg_bwd_mfma_kernel<4, 0>), dim3(grid), dim3(BLOCK), 0, s, a);
         return check_launch("aggregate backward (matrix cores)");
+    }
+    if (pl.pconv_mfma_shape && !agg_lds_only() && (ATOMIC || a.contrib || a.Ci == 0)) {
+        const int grid = (int)std::min<long long>(ceil_div(a.total, NWAVE), 256 * 64);
+        if (a.Cm == 16) hipLaunchKernelGGL((pconv_bwd_mfma_kernel<16, ATOMIC>), dim3(grid), dim3(BLOCK), 0, s, a);
+        else hipLaunchKernelGGL((pconv_bwd_mfma_kernel<4, ATOMIC>), dim3(grid), dim3(BLOCK), 0, s, a);
+        return check_launch("aggregate backward (matrix cores, unguided)");
     }
     if (pl.fixed_shape) return launch(agg_bwd_kernel<16, true, ATOMIC, true>, a, pl, s, "aggregate backward");
     switch (pl.cm_t) {

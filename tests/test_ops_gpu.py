@@ -79,6 +79,10 @@ PCONV_SHAPES = [
     (2, 70, 70, 4, 8, 4, 4),
     (1, 100, 100, 16, 16, 5, 16),      # Ca not a multiple of 4 -> scalar rows
     (1, 40, 40, 64, 16, 16, 16),       # K=64, the shape of test_kernels.py:1090-1094
+    (1, 300, 120, 16, 16, 16, 16),     # StridePE of the BASELINE configs, K = 16: unguided matrix-core kernels
+    (2, 90, 90, 16, 16, 16, 4),        # ... 10cm-lite (C_mid = 4), batch 2
+    (1, 200, 200, 16, 32, 16, 4),      # three channel tiles
+    (1, 150, 150, 16, 32, 0, 16),      # no appended features
 ]
 
 
@@ -184,6 +188,8 @@ LIN_SHAPES = [
     (2, 90, 90, 8, 8, 4, 4, 16),
     (1, 1000, 1000, 16, 3, 0, 16, 32),    # enough points for a split-K reduction of grad_lin_w
     (1, 64, 64, 16, 3, 0, 1, 5),          # J = 3: scalar GEMM loads
+    (1, 300, 120, 16, 16, 16, 4, 32),     # StridePE of the 10cm-lite model: unguided matrix-core kernels, CSR contribution rows
+    (2, 80, 80, 16, 16, 16, 16, 32),      # ... C_mid = 16, batch 2
     (2, 70, 110, 5, 192, 32, 1, 24),      # C_mid = 1 kernels: batch 2, odd K, 48 quads per row (not a power of two)
     (1, 50, 120, 16, 384, 32, 1, 40),     # C_mid = 1, widest decoder layer: two lane passes per row
     (1, 90, 60, 16, 8, 0, 1, 12),         # C_mid = 1, two quads per row: 32 list entries per wave step
