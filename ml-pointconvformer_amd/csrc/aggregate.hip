@@ -1099,7 +1099,7 @@ int aggregate_forward(const float* x, const int64_t* idx, const float* guid, con
     PCF_REQUIRE(idx && w && out, "aggregate forward: null pointer (idx=%p w=%p out=%p)", (const void*)idx,
                 (const void*)w, (void*)out);
     PCF_REQUIRE(Ca == 0 || add, "aggregate forward: Ca=%d but additional features pointer is null", Ca);
-    const bool al = aligned16(x) && aligned16(w) && aligned16(out) && (Ca == 0 || aligned16(add));
+    const bool al = aligned16(x) && aligned16(w) && aligned16(out) && (Ca == 0 || aligned16(add)) && (!guid || aligned16(guid));
     AggArgs a{};
     a.x = x; a.idx = idx; a.guid = guid; a.w = w; a.add = add; a.out = out;
     a.total = total; a.N = N; a.Nout = Nout; a.K = K; a.Ci = Ci; a.Ca = Ca; a.Cm = Cm; a.H = guid ? H : 1;
@@ -1142,7 +1142,8 @@ int aggregate_backward(const float* gout, const float* x, const int64_t* idx, co
                 "aggregate backward: need exactly one of grad_x / contrib");
     PCF_REQUIRE(!guid || gguid, "aggregate backward: grad_guid is null");
     PCF_REQUIRE(Ca == 0 || (add && gadd), "aggregate backward: Ca=%d but add/grad_add pointer is null", Ca);
-    const bool al = aligned16(x) && aligned16(w) && aligned16(gout) && aligned16(gw) && (Ca == 0 || aligned16(add));
+    const bool al = aligned16(x) && aligned16(w) && aligned16(gout) && aligned16(gw) && (Ca == 0 || (aligned16(add) && aligned16(gadd))) &&
+                    (!guid || (aligned16(guid) && aligned16(gguid))) && (!contrib || aligned16(contrib));
     AggArgs a{};
     a.x = x; a.idx = idx; a.guid = guid; a.w = w; a.add = add; a.gout = gout;
     a.gx = gx; a.contrib = contrib; a.gguid = gguid; a.gw = gw; a.gadd = gadd;
