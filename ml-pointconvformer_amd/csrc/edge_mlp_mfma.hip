@@ -476,8 +476,6 @@ bool rowlin_mfma_supported(const RowLin& a) {
     return true;
 }
 
-// A wave keeps one 16-row tile of loads in flight, so the latency hiding has to come from resident waves:
-// up to 2048 workgroups = 8 waves per SIMD (the kernels need 32-68 VGPRs).
 // A wave keeps one 16-row tile of loads in flight, so the latency hiding comes from resident waves: up to 2048
 // workgroups.  Against that, every workgroup pays a fixed prologue and (backward) writes a Cout x 16*TI partial of
 // dW -- 16 KB at Cin = 64 -- so wide-input layers get TI tiles per wave: at R = 80k, Cin = 64 that is 313
