@@ -45,6 +45,19 @@ const char* pcf_hip_version(void);
 /* Message of the last error returned on this thread ("" if none). */
 const char* pcf_hip_last_error(void);
 
+/* ---- diagnostics (no reference counterpart: the reference has one kernel per operator) --------------------------
+ * Launch log: while enabled, every kernel launch of the library appends one line (the kernel's name where a
+ * dispatcher chooses between variants, else the launch site's label).  _enable clears the log; _read copies the
+ * NUL-terminated text and clears it when `capacity` suffices, and always returns the bytes needed.  Tests use it to
+ * assert WHICH kernels a model configuration dispatches to. */
+void pcf_hip_launch_log_enable(int on);
+size_t pcf_hip_launch_log_read(char* buf, size_t capacity);
+/* Kernel family for the aggregate shapes the matrix-core kernels cover: 0 default, 1 LDS-tiled kernels (cross-check),
+ * 2 tiled matrix-core kernels everywhere.  Process-wide; the environment (PCF_AGG_LDS=1 / PCF_AGG_TILED=1) only sets
+ * the initial value. */
+int pcf_hip_set_aggregate_engine(int engine);
+int pcf_hip_get_aggregate_engine(void);
+
 /* ---- guided aggregate (PCF) ------------------------------------------------------------------
  * replaces pcf_cuda.pcf_forward / pcf_backward        (pcf_cuda.cpp:10-11, pcf.h:38-66,
  *                                                       pcf_ops.cu:27-71,87-141,143-202)

@@ -14,6 +14,7 @@
 // layout.  grad_x is either float-atomic scatter-add (no CSR available) or a plain
 // store of every edge's contribution row for the CSR gather-reduce in csr_reduce_kernel.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 
 #include "pcf_common.h"
@@ -1000,28 +1001,37 @@ static int launch(KernelT kernel, const AggArgs& a, const Plan& pl, hipStream_t 
     return check_launch(what);
 }
 
-// PCF_AGG_LDS=1 keeps the LDS kernels for the BASELINE shape (the cross-check of the matrix-core ones)
-static bool agg_lds_only() {
-    static const bool v = [] { const char* e = getenv("PCF_AGG_LDS"); return e && e[0] == '1'; }();
+// Which kernel family serves the shapes the matrix-core kernels cover: 0 = default dispatch, 1 = the LDS kernels (the
+// cross-check of the matrix-core ones), 2 = the tiled matrix-core kernels also where a loop-free instance exists
+// and the unguided C_mid = 4 forward.  Process-wide, set through pcf_hip_set_aggregate_engine(); the environment
+// (PCF_AGG_LDS=1 / PCF_AGG_TILED=1) only provides the initial value.
+static std::atomic<int> g_agg_engine{-1};
+static int agg_engine() {
+    int v = g_agg_engine.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* l = getenv("PCF_AGG_LDS");
+        const char* t = getenv("PCF_AGG_TILED");
+        v = (l && l[0] == '1') ? 1 : (t && t[0] == '1') ? 2 : 0;
+        g_agg_engine.store(v, std::memory_order_relaxed);
+    }
     return v;
 }
-
-// PCF_AGG_TILED=1 runs the BASELINE shape through the tiled kernels (test hook)
-static bool agg_tiled_only() {
-    static const bool v = [] { const char* e = getenv("PCF_AGG_TILED"); return e && e[0] == '1'; }();
-    return v;
-}
+static bool agg_lds_only() { return agg_engine() == 1; }
+static bool agg_tiled_only() { return agg_engine() == 2; }
 
 static int launch_fwd(const AggArgs& a, const Plan& pl, hipStream_t s) {
 #define PCF_FWD(CMV)                                                                   \
-    return pl.vrow ? launch(agg_fwd_kernel<CMV, true>, a, pl, s, "aggregate forward")  \
-                   : launch(agg_fwd_kernel<CMV, false>, a, pl, s, "aggregate forward")
+    return pl.vrow ? launch(agg_fwd_kernel<CMV, true>, a, pl, s, "agg_fwd_kernel<" #CMV ",true>")  \
+                   : launch(agg_fwd_kernel<CMV, false>, a, pl, s, "agg_fwd_kernel<" #CMV ",false>")
     if (pl.mfma_shape && !agg_lds_only()) {
         const int grid = (int)std::min<long long>(ceil_div(a.total, NWAVE), 256 * 64);
-        if (a.Cm == 16 && a.Ci == 16 && !agg_tiled_only()) hipLaunchKernelGGL(agg_fwd_fx_mfma_kernel, dim3(grid), dim3(BLOCK), 0, s, a);
-        else if (a.Cm == 16) hipLaunchKernelGGL((agg_fwd_mfma_kernel<16, 0>), dim3(grid), dim3(BLOCK), 0, s, a);
+        if (a.Cm == 16 && a.Ci == 16 && !agg_tiled_only()) {
+            hipLaunchKernelGGL(agg_fwd_fx_mfma_kernel, dim3(grid), dim3(BLOCK), 0, s, a);
+            return check_launch("agg_fwd_fx_mfma_kernel");
+        }
+        if (a.Cm == 16) hipLaunchKernelGGL((agg_fwd_mfma_kernel<16, 0>), dim3(grid), dim3(BLOCK), 0, s, a);
         else hipLaunchKernelGGL((agg_fwd_mfma_kernel<4, 0>), dim3(grid), dim3(BLOCK), 0, s, a);
-        return check_launch("aggregate forward (matrix cores)");
+        return check_launch(a.Cm == 16 ? "agg_fwd_mfma_kernel<16,0>" : "agg_fwd_mfma_kernel<4,0>");
     }
     // unguided forward: C_mid = 16 only (at C_mid = 4 the 64-byte output rows make the LDS kernel's coalesced stores
     // the better deal: 69 vs 82 us at 144k points, Ci = Ca = 16); PCF_AGG_TILED=1 forces it (tests)
@@ -1029,15 +1039,15 @@ static int launch_fwd(const AggArgs& a, const Plan& pl, hipStream_t s) {
         const int grid = (int)std::min<long long>(ceil_div(a.total, NWAVE), 256 * 64);
         if (a.Cm == 16) hipLaunchKernelGGL(pconv_fwd_mfma_kernel<16>, dim3(grid), dim3(BLOCK), 0, s, a);
         else hipLaunchKernelGGL(pconv_fwd_mfma_kernel<4>, dim3(grid), dim3(BLOCK), 0, s, a);
-        return check_launch("aggregate forward (matrix cores, unguided)");
+        return check_launch(a.Cm == 16 ? "pconv_fwd_mfma_kernel<16>" : "pconv_fwd_mfma_kernel<4>");
     }
-    if (pl.fixed_shape) return launch(agg_fwd_kernel<16, true, true>, a, pl, s, "aggregate forward");
+    if (pl.fixed_shape) return launch(agg_fwd_kernel<16, true, true>, a, pl, s, "agg_fwd_kernel<16,true,true>");
     switch (pl.cm_t) {
         case 1: PCF_FWD(1);
-        case 4: return launch(agg_fwd_kernel<4, true>, a, pl, s, "aggregate forward");
-        case 8: return launch(agg_fwd_kernel<8, true>, a, pl, s, "aggregate forward");
-        case 16: return launch(agg_fwd_kernel<16, true>, a, pl, s, "aggregate forward");
-        case 32: return launch(agg_fwd_kernel<32, true>, a, pl, s, "aggregate forward");
+        case 4: return launch(agg_fwd_kernel<4, true>, a, pl, s, "agg_fwd_kernel<4,true>");
+        case 8: return launch(agg_fwd_kernel<8, true>, a, pl, s, "agg_fwd_kernel<8,true>");
+        case 16: return launch(agg_fwd_kernel<16, true>, a, pl, s, "agg_fwd_kernel<16,true>");
+        case 32: return launch(agg_fwd_kernel<32, true>, a, pl, s, "agg_fwd_kernel<32,true>");
         default: PCF_FWD(0);
     }
 #undef PCF_FWD
@@ -1046,28 +1056,31 @@ static int launch_fwd(const AggArgs& a, const Plan& pl, hipStream_t s) {
 template <bool ATOMIC>
 static int launch_bwd_mode(const AggArgs& a, const Plan& pl, hipStream_t s) {
 #define PCF_BWD(CMV)                                                                            \
-    return pl.vrow ? launch(agg_bwd_kernel<CMV, true, ATOMIC>, a, pl, s, "aggregate backward")  \
-                   : launch(agg_bwd_kernel<CMV, false, ATOMIC>, a, pl, s, "aggregate backward")
+    return pl.vrow ? launch(agg_bwd_kernel<CMV, true, ATOMIC>, a, pl, s, "agg_bwd_kernel<" #CMV ",true>")  \
+                   : launch(agg_bwd_kernel<CMV, false, ATOMIC>, a, pl, s, "agg_bwd_kernel<" #CMV ",false>")
     if (pl.mfma_shape && ATOMIC && !agg_lds_only()) {
         const int grid = (int)std::min<long long>(ceil_div(a.total, NWAVE), 256 * 64);
-        if (a.Cm == 16 && a.Ci == 16 && !agg_tiled_only()) hipLaunchKernelGGL(agg_bwd_fx_mfma_kernel, dim3(grid), dim3(BLOCK), 0, s, a);
-        else if (a.Cm == 16) hipLaunchKernelGGL((agg_bwd_mfma_kernel<16, 0>), dim3(grid), dim3(BLOCK), 0, s, a);
+        if (a.Cm == 16 && a.Ci == 16 && !agg_tiled_only()) {
+            hipLaunchKernelGGL(agg_bwd_fx_mfma_kernel, dim3(grid), dim3(BLOCK), 0, s, a);
+            return check_launch("agg_bwd_fx_mfma_kernel");
+        }
+        if (a.Cm == 16) hipLaunchKernelGGL((agg_bwd_mfma_kernel<16, 0>), dim3(grid), dim3(BLOCK), 0, s, a);
         else hipLaunchKernelGGL((agg_bwd_mfma_kernel<4, 0>), dim3(grid), dim3(BLOCK), 0, s, a);
-        return check_launch("aggregate backward (matrix cores)");
+        return check_launch(a.Cm == 16 ? "agg_bwd_mfma_kernel<16,0>" : "agg_bwd_mfma_kernel<4,0>");
     }
     if (pl.pconv_mfma_shape && !agg_lds_only() && (ATOMIC || a.contrib || a.Ci == 0)) {
         const int grid = (int)std::min<long long>(ceil_div(a.total, NWAVE), 256 * 64);
         if (a.Cm == 16) hipLaunchKernelGGL((pconv_bwd_mfma_kernel<16, ATOMIC>), dim3(grid), dim3(BLOCK), 0, s, a);
         else hipLaunchKernelGGL((pconv_bwd_mfma_kernel<4, ATOMIC>), dim3(grid), dim3(BLOCK), 0, s, a);
-        return check_launch("aggregate backward (matrix cores, unguided)");
+        return check_launch(a.Cm == 16 ? "pconv_bwd_mfma_kernel<16>" : "pconv_bwd_mfma_kernel<4>");
     }
-    if (pl.fixed_shape) return launch(agg_bwd_kernel<16, true, ATOMIC, true>, a, pl, s, "aggregate backward");
+    if (pl.fixed_shape) return launch(agg_bwd_kernel<16, true, ATOMIC, true>, a, pl, s, "agg_bwd_kernel<16,true,fx>");
     switch (pl.cm_t) {
         case 1: PCF_BWD(1);
-        case 4: return launch(agg_bwd_kernel<4, true, ATOMIC>, a, pl, s, "aggregate backward");
-        case 8: return launch(agg_bwd_kernel<8, true, ATOMIC>, a, pl, s, "aggregate backward");
-        case 16: return launch(agg_bwd_kernel<16, true, ATOMIC>, a, pl, s, "aggregate backward");
-        case 32: return launch(agg_bwd_kernel<32, true, ATOMIC>, a, pl, s, "aggregate backward");
+        case 4: return launch(agg_bwd_kernel<4, true, ATOMIC>, a, pl, s, "agg_bwd_kernel<4,true>");
+        case 8: return launch(agg_bwd_kernel<8, true, ATOMIC>, a, pl, s, "agg_bwd_kernel<8,true>");
+        case 16: return launch(agg_bwd_kernel<16, true, ATOMIC>, a, pl, s, "agg_bwd_kernel<16,true>");
+        case 32: return launch(agg_bwd_kernel<32, true, ATOMIC>, a, pl, s, "agg_bwd_kernel<32,true>");
         default: PCF_BWD(0);
     }
 #undef PCF_BWD
@@ -1106,7 +1119,7 @@ int aggregate_forward(const float* x, const int64_t* idx, const float* guid, con
     if (agg1_covers(guid != nullptr, K, Ci, Ca, Cm)) {
         if (al) hipLaunchKernelGGL(agg1_fwd_kernel<true>, dim3(agg1_grid(total)), dim3(BLOCK), 0, stream, a);
         else hipLaunchKernelGGL(agg1_fwd_kernel<false>, dim3(agg1_grid(total)), dim3(BLOCK), 0, stream, a);
-        return check_launch("aggregate forward (C_mid = 1)");
+        return check_launch("agg1_fwd_kernel");
     }
     Plan pl;
     if (int e = make_plan(pl, false, guid != nullptr, total, K, Ci, Ca, Cm, H, al)) return e;
@@ -1120,7 +1133,7 @@ static int launch_agg1_bwd(const AggArgs& a, hipStream_t s) {
     const dim3 grid(agg1_grid(a.total));
     if (a.Ci + a.Ca <= 4 * WAVE) hipLaunchKernelGGL((agg1_bwd_kernel<AL, ATOMIC, 1>), grid, dim3(BLOCK), 0, s, a);
     else hipLaunchKernelGGL((agg1_bwd_kernel<AL, ATOMIC, 2>), grid, dim3(BLOCK), 0, s, a);
-    return check_launch("aggregate backward (C_mid = 1)");
+    return check_launch("agg1_bwd_kernel");
 }
 
 // Backward of both operators.  Exactly one of gx (atomic scatter; zeroed here) / contrib (per-edge
@@ -1167,7 +1180,7 @@ int csr_reduce(const float* contrib, const int32_t* inv_n, const uint8_t* inv_k,
     const int grid = (int)std::min<long long>((rows + NWAVE - 1) / NWAVE, 256 * 32);
     hipLaunchKernelGGL(csr_reduce_kernel, dim3(grid), dim3(BLOCK), 0, stream, contrib, inv_n, inv_k, inv_idx, gx, B, N,
                        Nout, K, Ci, inv_len, inv_idx_len);
-    return check_launch("csr gather-reduce");
+    return check_launch("csr_reduce_kernel");
 }
 
 // grad_x of the C_mid = 1 aggregate straight from its output gradient dout [B*Nout, J] (J = Ci + Ca) and the CSR.
@@ -1184,7 +1197,7 @@ int csr_gather1(const float* dout, const float* w, const int32_t* inv_n, const u
     if (Ci <= 4 * WAVE) { if (al) PCF_G1(true, 1); else PCF_G1(false, 1); }
     else { if (al) PCF_G1(true, 2); else PCF_G1(false, 2); }
 #undef PCF_G1
-    return check_launch("csr gather (C_mid = 1)");
+    return check_launch("csr_gather1_kernel");
 }
 
 }  // namespace pcf
@@ -1249,5 +1262,13 @@ int pcf_hip_pcf_backward_csr(const float* grad_out, const float* x, const int32_
         return e;
     return csr_reduce(contrib, inv_neighbors, inv_k, inv_idx, grad_x, B, N, Nout, K, Ci, inv_len, inv_idx_len, s);
 }
+
+int pcf_hip_set_aggregate_engine(int engine) {
+    if (engine < 0 || engine > 2) return pcf::fail(PCF_E_BADARG, "set_aggregate_engine: 0 (default), 1 (LDS) or 2 (tiled), got %d", engine);
+    pcf::g_agg_engine.store(engine, std::memory_order_relaxed);
+    return pcf::ok();
+}
+
+int pcf_hip_get_aggregate_engine(void) { return pcf::agg_engine(); }
 
 }  // extern "C"

@@ -20,6 +20,7 @@ char* err_buf();
 int fail(int code, const char* fmt, ...);
 inline int ok() { err_buf()[0] = 0; return PCF_OK; }
 int check_launch(const char* what);
+void note_launch(const char* what);
 
 #define PCF_REQUIRE(cond, ...)                                        \
     do {                                                              \

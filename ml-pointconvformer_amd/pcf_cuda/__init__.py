@@ -83,8 +83,41 @@ _knn_wave = _sig('pcf_hip_knn_wave', [_P] * 4 + [_I] * 3 + [_P] * 2)
 _gemm_nt = _sig('pcf_hip_gemm_nt', [_P] * 4 + [_I] * 3 + [_P])
 
 
+_log_enable = _sig('pcf_hip_launch_log_enable', [_I], None)
+_log_read = _sig('pcf_hip_launch_log_read', [ctypes.c_char_p, _Z], _Z)
+_set_engine = _sig('pcf_hip_set_aggregate_engine', [_I])
+_get_engine = _sig('pcf_hip_get_aggregate_engine', [])
+
+AGG_ENGINES = {'default': 0, 'lds': 1, 'tiled': 2}
+
+
 def library_path() -> str:
     return _LIB_PATH
+
+
+def launch_log(enable: bool):
+    """Start (clearing) or stop recording the names of the kernels the library launches (diagnostic / test hook)."""
+    _log_enable(1 if enable else 0)
+
+
+def read_launch_log():
+    """-> list of kernel / launch-site names recorded since the last read."""
+    n = _log_read(None, 0)
+    buf = ctypes.create_string_buffer(n + 65536)
+    _log_read(buf, len(buf))
+    return [l for l in buf.value.decode().split('\n') if l]
+
+
+def set_aggregate_engine(name: str):
+    """'default' | 'lds' | 'tiled': the kernel family behind pcf_forward/backward and pconv_* for the shapes the
+    matrix-core kernels cover (process-wide; the cross-checks of the test-suite toggle it)."""
+    if _set_engine(AGG_ENGINES[name]) != 0:
+        raise RuntimeError(_last_error().decode())
+
+
+def get_aggregate_engine() -> str:
+    v = _get_engine()
+    return next(k for k, e in AGG_ENGINES.items() if e == v)
 
 
 def version() -> str:

@@ -83,10 +83,15 @@ class GradBucket:
     gradients (13.7 k floats for the PCFLayer, 1.93 M for the 10cm-lite model) are packed into one contiguous buffer
     -- `pack()` is capturable: one concatenation, pre-scaled by 1/world -- summed over the ranks with a single
     RCCL all-reduce on the current stream, and `unpack()` copies the averages back into the .grad tensors with one
-    multi-tensor kernel.  Same result as DDP: the mean of the rank-local gradients."""
+    multi-tensor kernel.  Gradients: the mean of the rank-local gradients, as DDP.  Buffers (BatchNorm running
+    statistics and counters): DDP broadcasts rank 0's before every forward (`broadcast_buffers=True`); here they are
+    broadcast at construction (`broadcast_parameters`) and whenever the caller asks (`sync_buffers()`: once per step
+    to mirror DDP exactly, or before checkpointing from rank 0) -- the benchmark loops skip the per-step call because
+    running statistics do not enter a training-mode forward."""
 
-    def __init__(self, params):
+    def __init__(self, params, buffers=None):
         self.params = [p for p in params if p.requires_grad]
+        self.buffers = [b for b in (buffers or []) if b is not None]
         n = sum(p.numel() for p in self.params)
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.flat = torch.zeros(n, dtype=torch.float32, device=self.params[0].device)
@@ -96,10 +101,17 @@ class GradBucket:
             o += p.numel()
 
     def broadcast_parameters(self):
-        """Rank 0's parameters everywhere, as DDP does at construction."""
+        """Rank 0's parameters and buffers everywhere, as DDP does at construction."""
         if self.world > 1:
             for p in self.params:
                 dist.broadcast(p.data, 0)
+            self.sync_buffers()
+
+    def sync_buffers(self):
+        """Rank 0's buffers everywhere (DDP's broadcast_buffers)."""
+        if self.world > 1:
+            for b in self.buffers:
+                dist.broadcast(b, 0)
 
     def pack(self):
         grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]

@@ -186,6 +186,116 @@ _gdiff_fwd = _sig('pcf_hip_guidance_diff_forward', [_P] * 5 + [_I] * 7 + [_P])
 _gdiff_bwd = _sig('pcf_hip_guidance_diff_backward', [_P] * 5 + [_I] * 6 + [_P])
 
 
+def bn_momentum(bn):
+    """The factor of this step's running-statistics update: bn.momentum, or the cumulative average
+    1 / (num_batches_tracked + 1) when it is None (torch.nn.modules.batchnorm._BatchNorm.forward).  The counter is
+    read on the host only in that (non-default) case."""
+    if bn.momentum is not None:
+        return float(bn.momentum)
+    flush_bn_counters()
+    return 1.0 / (float(bn.num_batches_tracked) + 1.0) if bn.num_batches_tracked is not None else 0.0
+
+
+def same_bn_hyperparameters(bns):
+    """The fused chains take ONE eps and ONE momentum for all their BatchNorms: they apply only when the modules agree
+    (and use the plain exponential update, momentum not None)."""
+    return all(isinstance(b, torch.nn.modules.batchnorm._BatchNorm) and b.momentum is not None and b.eps == bns[0].eps
+               and b.momentum == bns[0].momentum and b.track_running_stats == bns[0].track_running_stats
+               and not cross_rank_bn(b) for b in bns)
+
+
+# --------------------------------------------------------------------------------------------------
+# SyncBatchNorm (every BASELINE YAML sets sync_bn: True; train_ScanNet_DDP_WarmUP.py:192-193 converts the model)
+# --------------------------------------------------------------------------------------------------
+_SYNC_WARNED = False
+
+
+def cross_rank_bn(bn):
+    """True when `bn` is a torch.nn.SyncBatchNorm whose batch statistics span more than one rank right now: the fused
+    kernels take batch statistics on-rank, so such a module goes through `sync_bn_act` (statistics exchanged with
+    torch.distributed) and is kept out of the fused chains.  In eval mode, or with one rank, SyncBatchNorm IS
+    BatchNorm and the fused path applies."""
+    global _SYNC_WARNED
+    if not isinstance(bn, torch.nn.SyncBatchNorm) or not (bn.training or bn.running_mean is None):
+        return False
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(bn.process_group) < 2:
+        return False
+    if not _SYNC_WARNED:
+        _SYNC_WARNED = True
+        import warnings
+        warnings.warn('pcf_layers: SyncBatchNorm over %d ranks -- batch statistics are exchanged per BatchNorm layer '
+                      '(as torch.nn.SyncBatchNorm does) and the fused edge chains, whose statistics are rank-local, '
+                      'are not used.  Set `sync_bn: False` for the fused path (per-rank statistics over the packed '
+                      'batch of each rank).' % dist.get_world_size(bn.process_group))
+    return True
+
+
+class _SyncBN(torch.autograd.Function):
+    """y = BN(z) over the last axis with statistics over ALL ranks of `group` (torch.nn.SyncBatchNorm semantics:
+    per-rank mean / M2 / count gathered and merged; backward all-reduces sum(dy) and sum(dy * xhat)).  Device-agnostic
+    host logic over torch.distributed -- runs on RCCL (GPU) and gloo (CPU tests)."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, running_mean, running_var, eps, momentum, group):
+        import torch.distributed as dist
+        C = z.shape[-1]
+        zr = z.reshape(-1, C)
+        n = zr.shape[0]
+        mean_l = zr.mean(0) if n else zr.new_zeros(C)
+        m2_l = ((zr - mean_l) ** 2).sum(0)
+        packed = torch.cat([mean_l, m2_l, zr.new_full((1,), float(n))])
+        world = dist.get_world_size(group)
+        parts = [torch.empty_like(packed) for _ in range(world)]
+        dist.all_gather(parts, packed, group=group)
+        allp = torch.stack(parts)
+        cnt = allp[:, 2 * C]
+        total = cnt.sum()
+        mean = (allp[:, :C] * cnt[:, None]).sum(0) / total
+        m2 = (allp[:, C:2 * C] + cnt[:, None] * (allp[:, :C] - mean) ** 2).sum(0)
+        var = m2 / total
+        rstd = torch.rsqrt(var + eps)
+        if running_mean is not None:
+            with torch.no_grad():
+                running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
+                running_var.mul_(1 - momentum).add_(m2 / torch.clamp(total - 1, min=1), alpha=momentum)
+        xhat = (z - mean) * rstd
+        ctx.save_for_backward(xhat, gamma, rstd, total)
+        ctx.group = group
+        return xhat * gamma + beta
+
+    @staticmethod
+    def backward(ctx, dy):
+        import torch.distributed as dist
+        xhat, gamma, rstd, total = ctx.saved_tensors
+        C = dy.shape[-1]
+        dyr, xr = dy.reshape(-1, C), xhat.reshape(-1, C)
+        sums = torch.cat([dyr.sum(0), (dyr * xr).sum(0)])
+        dbeta, dgamma = sums[:C].clone(), sums[C:].clone()          # rank-local: DDP averages parameter gradients
+        dist.all_reduce(sums, group=ctx.group)
+        dz = (dy - sums[:C] / total - xhat * (sums[C:] / total)) * (gamma * rstd)
+        return dz, dgamma, dbeta, None, None, None, None, None
+
+
+def sync_bn_act(z, bn, act):
+    """act(bn(z)) for a SyncBatchNorm whose statistics span several ranks (see cross_rank_bn)."""
+    momentum = bn_momentum(bn)
+    if bn.running_mean is not None:
+        count_batch(bn)
+    y = _SyncBN.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, momentum, bn.process_group)
+    return _act_torch(y, act)
+
+
+def _act_torch(y, act):
+    if act == ACT_RELU:
+        return torch.relu(y)
+    if act == ACT_LEAKY:
+        return torch.nn.functional.leaky_relu(y, 0.1)
+    if act == ACT_SIGMOID:
+        return torch.sigmoid(y)
+    return y
+
+
 def rowlin_supported(cin, cout):
     """Layers the fused row-linear kernels are the better choice for: both widths <= 64 and at most four
     16x16 weight tiles (the matrix-core kernels keep W in registers); wider products go through the
@@ -276,10 +386,13 @@ def linear_bn_act(x, weight, bias, bn, act, training, gadd=None, gidx=None, grou
         _check_input(gidx, 'gidx', torch.int64)
     if bn is None:
         return _LinearBNAct.apply(x, weight, bias, None, None, None, None, 0.0, 0.0, False, act, gadd, gidx, group)
+    if cross_rank_bn(bn):
+        z = _LinearBNAct.apply(x, weight, bias, None, None, None, None, 0.0, 0.0, False, ACT_NONE, gadd, gidx, group)
+        return sync_bn_act(z, bn, act)
     use_batch = training or bn.running_mean is None
+    momentum = bn_momentum(bn) if training else 0.0     # before the counter moves (torch: factor = 1 / new count)
     if training:
         count_batch(bn)
-    momentum = 0.1 if bn.momentum is None else bn.momentum
     return _LinearBNAct.apply(x, weight, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, momentum,
                               use_batch, act, gadd, gidx, group)
 
@@ -423,10 +536,14 @@ def wide_linear_bn_act(x, weight, bias, bn, act, training, residual=None):
         raise RuntimeError('wide_linear_bn_act: more than 2^31 rows')
     if bn is None:
         return _WideLinearBNAct.apply(x, weight, bias, None, None, None, None, 0.0, 0.0, False, act, residual)
+    if cross_rank_bn(bn):
+        z = _WideLinearBNAct.apply(x, weight, bias, None, None, None, None, 0.0, 0.0, False, ACT_NONE, None)
+        y = sync_bn_act(z, bn, ACT_NONE if residual is not None else act)
+        return y if residual is None else _act_torch(y + residual, act)
     use_batch = training or bn.running_mean is None
+    momentum = bn_momentum(bn) if training else 0.0     # before the counter moves (torch: factor = 1 / new count)
     if training:
         count_batch(bn)
-    momentum = 0.1 if bn.momentum is None else bn.momentum
     return _WideLinearBNAct.apply(x, weight, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, momentum,
                                   use_batch, act, residual)
 
@@ -483,10 +600,12 @@ def bn_act(z, bn, act, training):
     _floats(z=z)
     if bn.weight is None:
         raise RuntimeError('bn_act: BatchNorm without affine parameters is not covered')
+    if cross_rank_bn(bn):
+        return sync_bn_act(z, bn, act)
     use_batch = training or bn.running_mean is None
+    momentum = bn_momentum(bn) if training else 0.0
     if training and bn.running_mean is not None:
         count_batch(bn)
-    momentum = 0.1 if bn.momentum is None else bn.momentum
     return _BNAct.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, momentum, use_batch, act)
 
 
@@ -575,7 +694,7 @@ class _PCFChain(torch.autograd.Function):
         Ws, bs, gammas, betas = keep[0::4], keep[1::4], keep[2::4], keep[3::4]
         rm = _ptr_array([bn.running_mean for bn in bns]) if training else None
         rv = _ptr_array([bn.running_var for bn in bns]) if training else None
-        mom = bns[0].momentum if bns[0].momentum is not None else 0.1
+        mom = bns[0].momentum               # same_bn_hyperparameters(): one eps / momentum for the chain, not None
         with _guard(dev):
             _call(_chain_fwd, _ptr(vi), _ptr(idx), _ptr(u), E, M * K, N, K, cv, g, heads, cm, _ptr_array(Ws), _ptr_array(bs),
                   _ptr_array(gammas), _ptr_array(betas), rm, rv, float(bns[0].eps), float(mom), 1 if training else 0,
@@ -661,7 +780,7 @@ class _WeightNetChain(torch.autograd.Function):
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         rm = _ptr_array([bn.running_mean for bn in bns]) if training else None
         rv = _ptr_array([bn.running_var for bn in bns]) if training else None
-        mom = bns[0].momentum if bns[0].momentum is not None else 0.1
+        mom = bns[0].momentum               # same_bn_hyperparameters(): one eps / momentum for the chain, not None
         with _guard(dev):
             _call(_wn_fwd, _ptr(x), E, cin, cm, _ptr_array(Ws), _ptr_array(bs), _ptr_array(gammas), _ptr_array(betas), rm, rv,
                   float(bns[0].eps), float(mom), 1 if training else 0, stats.data_ptr(), _ptr(a2_acc), _ptr(w),

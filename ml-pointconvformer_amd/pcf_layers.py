@@ -310,6 +310,8 @@ class WeightNet(pcf_fused.CounterScope):
         w = localized_xyz
         convs = list(self.mlp_convs)
         if len(convs) == 3 and not w.requires_grad and not getattr(self, 'no_chain', False) \
+                and (self.training or not torch.is_grad_enabled()) \
+                and pcf_fused.same_bn_hyperparameters([m.bn for m in convs]) \
                 and pcf_fused.weightnet_chain_supported(convs[0].c.in_features, (convs[0].c.out_features, convs[1].c.out_features),
                                                         convs[2].c.out_features, w.numel() // max(1, w.shape[-1])):
             # the three layers in one fused chain (four passes forward, three backward; csrc/edge_chain*.hip)
@@ -333,10 +335,46 @@ def _edge_geometry(cfg_use_vi, ref_xyz, ref_norm, nei_inds, ctr_xyz, ctr_norm, v
     return rel, (vi if cfg_use_vi else rel)
 
 
+class DropPath(nn.Module):
+    """Stochastic depth per sample (timm.models.layers.DropPath, which layers.py:9 imports and :237-238, :571-572,
+    :951-952 instantiate): in training the residual branch of a sample is dropped with probability `drop_prob` and
+    scaled by 1/keep otherwise; identity in eval.  One Bernoulli draw per batch row -- with the packed B = 1 layout
+    (layers.py:216) that is one draw per block call.  The draw stays on the device (no host sync, capturable)."""
+
+    def __init__(self, drop_prob: float = 0., scale_by_keep: bool = True):
+        super().__init__()
+        self.drop_prob, self.scale_by_keep = float(drop_prob), scale_by_keep
+
+    def draw(self, x):
+        """-> the per-sample factor [B, 1, ...] (0 or 1/keep), or None when the module is the identity."""
+        if self.drop_prob == 0. or not self.training:
+            return None
+        keep = 1. - self.drop_prob
+        m = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep)
+        if keep > 0. and self.scale_by_keep:
+            m.div_(keep)
+        return m
+
+    def forward(self, x):
+        m = self.draw(x)
+        return x if m is None else x * m
+
+    def extra_repr(self):
+        return f'drop_prob={round(self.drop_prob, 3):0.3f}'
+
+
 def _drop_path(cfg):
-    if getattr(cfg, 'drop_path_rate', 0.) > 0.:
-        raise NotImplementedError('drop_path_rate > 0 needs timm.DropPath; every BASELINE config uses 0')
-    return nn.Identity()
+    rate = float(getattr(cfg, 'drop_path_rate', 0.))
+    return DropPath(rate) if rate > 0. else nn.Identity()
+
+
+def _residual_tail(block, drop_path, x, shortcut, act):
+    """act(drop_path(block(x)) + shortcut)  (layers.py:414, :739).  Without a drop the sum and the activation ride in
+    the block's BatchNorm kernel; with one the branch is scaled by the drawn per-sample factor first."""
+    m = drop_path.draw(x) if isinstance(drop_path, DropPath) else None
+    if m is None:
+        return block.forward_residual(x, shortcut, act)
+    return _apply_act(block(x) * m + shortcut, act)
 
 
 class PCFLayer(pcf_fused.CounterScope):
@@ -368,6 +406,10 @@ class PCFLayer(pcf_fused.CounterScope):
         if getattr(self.cfg, 'NO_EDGE_CHAIN', False) or getattr(self.cfg, 'DETERMINISTIC_BACKWARD', False) \
                 or not isinstance(self.guidance_weight, MultiHeadGuidance) or self.guidance_weight.layer_norm:
             return None
+        # the chain's backward restarts from batch statistics and returns no gradient for the VI descriptor: eval-mode
+        # forward under autograd (frozen-BN fine-tuning, saliency) and a differentiable descriptor go layer by layer
+        if (not self.training and torch.is_grad_enabled()) or wn_in.requires_grad:
+            return None
         gw, wn = self.guidance_weight.mlp, self.weightnet.mlp_convs
         mods = [self.mlp_conv] + list(gw) + list(wn)
         if len(gw) != 2 or len(wn) != 3 or not all(isinstance(m, Linear_BN) for m in mods):
@@ -377,6 +419,8 @@ class PCFLayer(pcf_fused.CounterScope):
         if not pcf_fused.pcf_chain_supported(wn_in.shape[-1], self.mlp_conv.c.out_features, gw[1].c.out_features,
                                              wn[2].c.out_features, nei_inds.shape[2], hidden_ok, nei_inds.numel(),
                                              nei_inds.shape[1] * nei_inds.shape[2]):
+            return None
+        if not pcf_fused.same_bn_hyperparameters([m.bn for m in mods]):
             return None
         return [(m.c, m.bn) for m in mods]
 
@@ -424,9 +468,9 @@ class PCFLayer(pcf_fused.CounterScope):
                               inv_neighbors, inv_k, inv_idx)
         sparse_feats = pcf_fused.gather_max(dense_feats, nei_inds) if strided else dense_feats
         shortcut = self.unary_shortcut(sparse_feats)
-        # leaky_relu(drop_path(unary2(.)) + shortcut): drop_path is the identity (rate 0 in every BASELINE config)
-        new_feat = self.unary2.forward_residual(self.dropout(_linear_act(self.linear, agg, pcf_fused.ACT_RELU)), shortcut,
-                                                pcf_fused.ACT_LEAKY)
+        # leaky_relu(drop_path(unary2(.)) + shortcut)   (layers.py:397-414; drop_path_rate 0.2 in configPCF_2cm_PTF2)
+        new_feat = _residual_tail(self.unary2, self.drop_path, self.dropout(_linear_act(self.linear, agg, pcf_fused.ACT_RELU)),
+                                  shortcut, pcf_fused.ACT_LEAKY)
         return new_feat, wn_in
 
 
@@ -534,7 +578,7 @@ class PointConvStridePE(_ConvTail):
         y = self._aggregate_linear(feats_x, nei_inds, weights, feat_pe, inv_neighbors, inv_k, inv_idx)
         sparse_feats = pcf_fused.gather_max(dense_feats, nei_inds) if strided else dense_feats
         shortcut = self.unary_shortcut(sparse_feats)
-        return self.unary2.forward_residual(self.dropout(y), shortcut, pcf_fused.ACT_LEAKY), wn_in
+        return _residual_tail(self.unary2, self.drop_path, self.dropout(y), shortcut, pcf_fused.ACT_LEAKY), wn_in
 
 
 class PointConv(_ConvTail):

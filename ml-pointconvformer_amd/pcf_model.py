@@ -130,6 +130,34 @@ class PCF_Backbone(pcf_fused.CounterScope):
         return feats
 
 
+# Backbone presets (model_architecture.py:248-342): name -> (levels, heads, blocks per level, C_mid, grid-size ratios)
+_PRESETS = {
+    'PCF_Tiny': (5, 1, [0, 1, 1, 1, 1], 4, [1, 2, 4, 8, 16]),
+    'PCF_Small': (5, 8, [0, 2, 2, 2, 2], 4, [1, 2, 4, 8, 16]),
+    'PCF_Normal': (5, 8, [0, 2, 4, 6, 6], 16, [1, 2, 4, 8, 16]),
+    'PCF_Large': (6, 8, [0, 2, 4, 6, 6, 2], 16, [1, 2.5, 5, 10, 20, 40]),
+}
+
+
+def _preset(name):
+    levels, heads, blocks, cmid, ratios = _PRESETS[name]
+
+    def factory(input_grid_size, base_dim=64):
+        """-> (PCF_Backbone, cfg) for the voxel size of the finest resolution (0.02 / 0.05 / 0.1 ...)."""
+        cfg = get_default_configs(Config(), num_level=levels, base_dim=base_dim)
+        cfg.guided_level, cfg.num_heads = 0, heads
+        cfg.resblocks = list(blocks)
+        cfg.mid_dim = [cmid] * levels
+        cfg.grid_size = [input_grid_size * r for r in ratios]
+        return PCF_Backbone(cfg), cfg
+
+    factory.__name__ = factory.__qualname__ = name
+    return factory
+
+
+PCF_Tiny, PCF_Small, PCF_Normal, PCF_Large = (_preset(n) for n in ('PCF_Tiny', 'PCF_Small', 'PCF_Normal', 'PCF_Large'))
+
+
 class PointConvFormer_Segmentation(pcf_fused.CounterScope):
     def __init__(self, cfg):
         super().__init__()

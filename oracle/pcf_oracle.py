@@ -321,8 +321,9 @@ def _geometry(dense_xyz, dense_norm, idx, sparse_xyz, sparse_norm, use_vi, vi=No
 
 
 def pcf_layer(P: Params, dense_xyz, dense_feats, idx, dense_norm, sparse_xyz=None, sparse_norm=None,
-              vi=None, num_heads=8, use_vi=True):
-    """PCFLayer.forward.   (layers.py:306-416)  Returns (new_feat, weightNetInput)."""
+              vi=None, num_heads=8, use_vi=True, drop_scale=None):
+    """PCFLayer.forward.   (layers.py:306-416)  Returns (new_feat, weightNetInput).  drop_scale: the factor DropPath
+    drew for the residual branch (0 or 1/keep; timm DropPath with one sample per packed batch), None = identity."""
     B, N, _ = dense_xyz.shape
     M = N if sparse_xyz is None else sparse_xyz.shape[1]
     K = idx.shape[2]
@@ -343,6 +344,8 @@ def pcf_layer(P: Params, dense_xyz, dense_feats, idx, dense_norm, sparse_xyz=Non
     short = dense_feats if sparse_xyz is None else gather_rows(dense_feats, idx).max(2)[0]
     if P.has('unary_shortcut.mlp.c.weight'):
         short = unary_block(short, P.sub('unary_shortcut'), relu=False)
+    if drop_scale is not None:          # layers.py:414
+        y = y * drop_scale
     return F.leaky_relu(y + short, 0.1), wn_in
 
 
@@ -397,8 +400,8 @@ def pointconv_layer(P: Params, dense_xyz, dense_feats, idx, dense_norm=None, spa
 
 
 def pointconv_stride_pe_layer(P: Params, dense_xyz, dense_feats, idx, dense_norm, sparse_xyz=None,
-                              sparse_norm=None, vi=None, use_vi=True):
-    """PointConvStridePE.forward.   (layers.py:631-741)"""
+                              sparse_norm=None, vi=None, use_vi=True, drop_scale=None):
+    """PointConvStridePE.forward.   (layers.py:631-741; drop_scale as in pcf_layer, :739)"""
     fx = unary_block(dense_feats, P.sub('unary1')) if P.has('unary1.mlp.c.weight') else dense_feats
     rel, wn_in = _geometry(dense_xyz, dense_norm, idx, sparse_xyz, sparse_norm, use_vi, vi)
     pe = weightnet(rel, P.sub('pe_convs'))
@@ -409,6 +412,8 @@ def pointconv_stride_pe_layer(P: Params, dense_xyz, dense_feats, idx, dense_norm
     short = dense_feats if sparse_xyz is None else gather_rows(dense_feats, idx).max(2)[0]
     if P.has('unary_shortcut.mlp.c.weight'):
         short = unary_block(short, P.sub('unary_shortcut'), relu=False)
+    if drop_scale is not None:
+        y = y * drop_scale
     return F.leaky_relu(y + short, 0.1), wn_in
 
 
@@ -431,3 +436,61 @@ def pointconv_transpose_pe_layer(P: Params, sparse_xyz, sparse_feats, idx, spars
         y = F.relu(maybe_linear_bn(y, P.sub(f'mlp2_convs.{i}')))
         i += 1
     return y, wn_in
+
+
+# --------------------------------------------------------------------------------------
+# whole model (model_architecture.py:175-245 backbone forward, :406-502 segmentation forward)
+# --------------------------------------------------------------------------------------
+def segmentation_model(P: Params, cfg, features, pointclouds, edges_self, edges_forward, edges_propagate, norms,
+                       drop_scales=None):
+    """PointConvFormer_Segmentation.forward for transformer_type 'PCF' -> logits [1, N0, num_classes].
+
+    cfg: the model config (num_level, guided_level, resblocks, resblocks_back, num_heads, use_level_1, USE_XYZ, USE_VI,
+    USE_PE).  Which blocks exist is read from the parameter names, as the reference's constructor decides them
+    (:113-165, :376-398).  drop_scales: {block prefix: DropPath factor} for blocks whose residual branch is scaled."""
+    use_vi, use_pe, H = cfg.USE_VI is True, bool(cfg.USE_PE), cfg.num_heads
+    ds = drop_scales or {}
+    B = P.sub('pcf_backbone')
+
+    def block(Q, *args, **kw):
+        """A guided (PCFLayer) or unguided (PointConvStridePE) block, by the parameters it holds."""
+        if Q.has('guidance_unary.mlp.c.weight'):
+            return pcf_layer(Q, *args, num_heads=H, use_vi=use_vi, drop_scale=ds.get(Q.p[:-1]), **kw)
+        return pointconv_stride_pe_layer(Q, *args, use_vi=use_vi, drop_scale=ds.get(Q.p[:-1]), **kw)
+
+    x = torch.cat([features, pointclouds[0]], -1) if cfg.USE_XYZ else features
+    if cfg.use_level_1:                                                                  # :193-198
+        x, vi = pointconv_layer(B.sub('selfpointconv'), pointclouds[0], x, edges_self[0], norms[0], use_vi=use_vi,
+                                use_pe=use_pe)
+        for name in ('selfpointconv_res1', 'selfpointconv_res2'):
+            x, _ = pointconv_stride_pe_layer(B.sub(name), pointclouds[0], x, edges_self[0], norms[0], vi=vi, use_vi=use_vi,
+                                             drop_scale=ds.get(B.sub(name).p[:-1]))
+    else:                                                                                # :199-202
+        x = F.relu(linear_bn(x, B.sub('selfmlp')))
+    feats = [x]
+    for i in range(cfg.num_level - 1):                                                   # :204-243
+        x, _ = block(B.sub(f'pointconv.{i}'), pointclouds[i], feats[-1], edges_forward[i], norms[i], pointclouds[i + 1],
+                     norms[i + 1])
+        vi, j = None, 0
+        while B.has(f'pointconv_res.{i}.{j}.unary2.mlp.c.weight'):
+            x, vi_new = block(B.sub(f'pointconv_res.{i}.{j}'), pointclouds[i + 1], x, edges_self[i + 1], norms[i + 1], vi=vi)
+            vi = vi_new if vi is None else vi
+            j += 1
+        feats.append(x)
+    x = feats[-1]
+    for i in range(cfg.num_level - 1):                                                   # :448-498
+        lvl = cfg.num_level - 2 - i
+        x, _ = pointconv_transpose_pe_layer(P.sub(f'pointdeconv.{i}'), pointclouds[lvl + 1], x, edges_propagate[lvl],
+                                            norms[lvl + 1], pointclouds[lvl], norms[lvl], feats[lvl], use_vi=use_vi,
+                                            use_pe=use_pe)
+        vi, j = None, 0
+        while P.has(f'pointdeconv_res.{i}.{j}.unary2.mlp.c.weight'):
+            Q = P.sub(f'pointdeconv_res.{i}.{j}')
+            x, vi_new = pointconv_stride_pe_layer(Q, pointclouds[lvl], x, edges_self[lvl], norms[lvl], vi=vi, use_vi=use_vi,
+                                                  drop_scale=ds.get(Q.p[:-1]))
+            vi = vi_new if vi is None else vi
+            j += 1
+        feats[lvl] = x
+    x = F.relu(linear_bn(x, P.sub('fc1')))                                               # :500-501 (dropout_fc = 0)
+    return F.linear(x, P['fc2.weight'], P['fc2.bias'])
+

@@ -199,3 +199,79 @@ def test_point_transformer_layer(name):
     out.backward(g['gup'])
     torch.testing.assert_close(feats.grad, g['gin.feats'], **TOL)
     _check_param_grads(g, sd)
+
+
+def _model_table(g, dtype=torch.float32):
+    """cfg, {name: tensor} of synthetic parameters + default buffers for the model of fixture g (shapes from the build's
+    own model definition, constructed on the CPU: only its forward needs the GPU)."""
+    import model_fixture as MF
+    import pcf_model
+    cfg = MF.model_cfg(g)
+    c2 = pcf_model.Config(cfg)
+    c2.PCONV_OPT, c2.USE_CUDA_KERNEL = False, True
+    net = pcf_model.PointConvFormer_Segmentation(c2)
+    shapes = {k: tuple(v.shape) for k, v in net.named_parameters()}
+    assert sorted(shapes) == sorted(MF.reference_parameter_names(g))
+    assert sum(p.numel() for p in net.parameters()) == int(g['meta.n_params'])
+    table = {k: v.to(dtype).requires_grad_(True) for k, v in MF.synthetic_state(shapes).items()}
+    for k, b in net.named_buffers():
+        table[k] = b.clone().to(dtype) if b.is_floating_point() else b.clone()
+    return cfg, shapes, table
+
+
+@pytest.mark.parametrize('tag', ['lite', '10cm', '2cm'])
+def test_whole_model_at_real_widths(tag):
+    """oracle.segmentation_model against the reference model at the real widths of the BASELINE YAMLs
+    (tests/golden/make_golden_models.py), both in float64 so that the comparison is not drowned in the rounding
+    amplification of the 29-layer backward: logits, feature gradient, every parameter gradient (whole or sampled) to
+    1e-6 of the scale; then in float32 the logits to 5e-4.  The 2cm fixture runs with drop_path_rate 0.2 under the
+    recorded keep mask."""
+    import model_fixture as MF
+    g = MF.load(tag)
+    cfg, shapes, table = _model_table(g, torch.float64)
+    feats, pcs, es, ef, ep, nrms = MF.inputs(g)
+    feats = feats.detach().double().requires_grad_(True)
+    out = O.segmentation_model(O.Params(table, '', True), cfg, feats, [p.double() for p in pcs], es, ef, ep,
+                               [n.double() for n in nrms], drop_scales=MF.drop_factors(g))
+    torch.testing.assert_close(out.float(), g['out'], rtol=1e-5, atol=1e-5)
+    out.backward(g['gup'].double())
+    torch.testing.assert_close(feats.grad.float(), g['gin.features'], rtol=1e-5, atol=1e-5 * float(g['gin.features'].abs().max()))
+    bad = MF.bad_parameter_grads(((k, table[k].grad) for k in shapes), g, rtol=1e-5, atol=1e-5, noise_mult=0.0)
+    assert not bad, bad[:8]
+    cfg, shapes, table = _model_table(g, torch.float32)
+    feats, pcs, es, ef, ep, nrms = MF.inputs(g)
+    out = O.segmentation_model(O.Params(table, '', True), cfg, feats, pcs, es, ef, ep, nrms, drop_scales=MF.drop_factors(g))
+    torch.testing.assert_close(out, g['out'], rtol=5e-4, atol=5e-4)
+
+
+@pytest.mark.parametrize('tag', ['lite', '10cm', '2cm'])
+def test_model_blocks_at_real_widths(tag):
+    """Every block of the model on its own (parameters and neighbourhoods of the model, synthetic features and upstream
+    gradient): the oracle's layer functions in float32 against the reference block's float64 output, input gradients
+    and parameter gradients, 1e-3 (BASELINE's bar; in practice ~1e-5)."""
+    import model_fixture as MF
+    g = MF.load(tag)
+    cfg, shapes, table = _model_table(g)
+    _, pcs, es, ef, ep, nrms = MF.inputs(g)
+    drops = MF.drop_factors(g)
+    H, pe = cfg.num_heads, cfg.USE_PE
+    for name, kind, lin, lout, cin, cout in MF.block_plan(cfg):
+        feats, skip, up, edges = MF.block_case(g, name, kind, lin, lout, cin, cout)
+        P = O.Params(table, name + '.', True)
+        guided = P.has('guidance_unary.mlp.c.weight')
+        if kind == 'pointconv':
+            out, _ = O.pointconv_layer(P, pcs[lin], feats, edges, nrms[lin], use_vi=True, use_pe=pe)
+        elif kind == 'up':
+            out, _ = O.pointconv_transpose_pe_layer(P, pcs[lin], feats, edges, nrms[lin], pcs[lout], nrms[lout], skip, use_pe=pe)
+        else:
+            sp = (pcs[lout], nrms[lout]) if kind == 'down' else (None, None)
+            fn = O.pcf_layer if guided else O.pointconv_stride_pe_layer
+            kw = dict(num_heads=H) if guided else {}
+            out, _ = fn(P, pcs[lin], feats, edges, nrms[lin], *sp, drop_scale=drops.get(name), **kw)
+        pre = name + '.'
+        mine = [k for k in shapes if k.startswith(pre)]
+        for k in mine:
+            table[k].grad = None
+        out.backward(up)
+        bad = MF.block_mismatch(g, name, out, feats, skip, ((k[len(pre):], table[k].grad) for k in mine))
+        assert not bad, (name, bad[:6])
