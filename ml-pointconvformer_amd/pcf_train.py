@@ -23,6 +23,37 @@ import torch
 import knn_post_dataloader_utils as knn_utils
 
 
+# The model + optimisation keys of the four model YAMLs BASELINE.json names (values restated from
+# configs/configPCF_10cm_lite.yaml, configPCF_10cm.yaml, configPCF_5cm.yaml, configPCF_2cm_PTF2.yaml); `scene_points` /
+# `scenes` are the synthetic scene size and per-GPU batch the benchmark uses for each (BASELINE.json configs[1..4]:
+# 40k-point scenes for lite, ScanNet 10 cm ~ 40k-80k, 5 cm ~ 150k, 2 cm crops of <= 120k points, BATCH_SIZE 2).
+_COMMON = dict(BATCH_NORM=True, USE_XYZ=True, USE_PE=True, point_dim=3, num_level=5, base_dim=64,
+               feat_dim=[64, 128, 192, 256, 384], guided_level=0, num_heads=8, resblocks_back=[0, 0, 0, 0, 0],
+               K_self=[16] * 5, K_forward=[16] * 5, K_propagate=[16] * 5, num_classes=20, label_smoothing=0.2,
+               adamw_decay=0.05, ignore_label=-100, dropout_rate=0., dropout_fc=0., layer_norm_guidance=False,
+               sync_bn=True, use_level_1=True, drop_path_rate=0., mid_dim_back=1)
+BASELINE_CONFIGS = {
+    'configPCF_10cm_lite': dict(_COMMON, grid_size=[0.1, 0.2, 0.4, 0.8, 1.6], mid_dim=[4] * 5, resblocks=[0, 3, 3, 3, 3],
+                                learning_rate=0.02, scene_points=40000, scenes=4),
+    'configPCF_10cm': dict(_COMMON, grid_size=[0.1, 0.2, 0.4, 0.8, 1.6], mid_dim=[16] * 5, resblocks=[0, 2, 4, 6, 6],
+                           learning_rate=0.02, scene_points=40000, scenes=4),
+    'configPCF_5cm': dict(_COMMON, grid_size=[0.05, 0.1, 0.2, 0.4, 0.8], mid_dim=[16] * 5, resblocks=[0, 2, 4, 6, 6],
+                          learning_rate=0.01, scene_points=150000, scenes=1),
+    'configPCF_2cm_PTF2': dict(_COMMON, grid_size=[0.02, 0.06, 0.15, 0.375, 0.9375], mid_dim=[16] * 5, mid_dim_back=3,
+                               resblocks=[0, 2, 4, 6, 6, 2], use_level_1=False, drop_path_rate=0.2, learning_rate=0.01,
+                               scene_points=120000, scenes=2),
+}
+
+
+def baseline_config(name):
+    """-> pcf_model.Config for one of the BASELINE model YAMLs, defaults filled, both kernel switches on."""
+    import pcf_model
+    cfg = pcf_model.Config({k: (list(v) if isinstance(v, list) else v) for k, v in BASELINE_CONFIGS[name].items()})
+    pcf_model.get_default_configs(cfg, num_level=cfg.num_level, base_dim=cfg.base_dim)
+    cfg.PCONV_OPT, cfg.USE_CUDA_KERNEL = True, True
+    return cfg
+
+
 def _voxelize_first(xyz, grid):
     """One point per occupied voxel of edge `grid` (the first in index order) -> indices, ascending: the deterministic
     mode of util/voxelize.py:44-82, which thins the raw scan to the level-0 resolution."""

@@ -118,3 +118,192 @@ def test_ddp_two_ranks_gloo():
         assert slow == 2.0 and rate == pytest.approx(2 * 96 * 3 / 2.0)
         for n, gexp in want.items():
             torch.testing.assert_close(torch.from_numpy(grads[n]), gexp, rtol=1e-5, atol=1e-6, msg=lambda m, n=n: f'{n}: {m}')
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# SyncBatchNorm statistics over ranks, GradBucket buffers, and a whole-model training step under DDP
+# ---------------------------------------------------------------------------------------------------------------
+def _sync_bn_worker(rank, world, port, out):
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    import pcf_dist
+    import pcf_fused
+    pcf_dist.setup('gloo')
+    g = torch.Generator().manual_seed(5)
+    R, C = 200, 12
+    z = torch.randn(R, C, generator=g) * 2 + 3
+    up = torch.randn(R, C, generator=g)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    cut = [0, 70, R]                                   # unequal shares
+    lo, hi = cut[rank], cut[rank + 1]
+    bn = torch.nn.SyncBatchNorm(C)
+    with torch.no_grad():
+        bn.weight.copy_(gamma)
+        bn.bias.copy_(beta)
+    bn.train()
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        assert pcf_fused.cross_rank_bn(bn)
+        zl = z[lo:hi].clone().requires_grad_(True)
+        y = pcf_fused.sync_bn_act(zl, bn, pcf_fused.ACT_LEAKY)
+    y.backward(up[lo:hi])
+    # single-process reference on the whole batch
+    ref = torch.nn.BatchNorm1d(C)
+    with torch.no_grad():
+        ref.weight.copy_(gamma)
+        ref.bias.copy_(beta)
+    zf = z.clone().requires_grad_(True)
+    yf = torch.nn.functional.leaky_relu(ref(zf), 0.1)
+    yf.backward(up)
+    torch.testing.assert_close(y.detach(), yf.detach()[lo:hi], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(zl.grad, zf.grad[lo:hi], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(bn.running_mean, ref.running_mean, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(bn.running_var, ref.running_var, rtol=1e-5, atol=1e-6)
+    dg, db = bn.weight.grad.clone(), bn.bias.grad.clone()      # rank-local parts: their sum is the full-batch gradient
+    dist.all_reduce(dg)
+    dist.all_reduce(db)
+    torch.testing.assert_close(dg, ref.weight.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(db, ref.bias.grad, rtol=1e-4, atol=1e-4)
+    assert int(bn.num_batches_tracked) == 1
+    # eval mode: SyncBatchNorm is BatchNorm, no exchange
+    bn.eval()
+    assert not pcf_fused.cross_rank_bn(bn)
+    # GradBucket: buffers follow rank 0 (DDP's broadcast_buffers)
+    lin = torch.nn.Sequential(torch.nn.Linear(3, 3), torch.nn.BatchNorm1d(3))
+    with torch.no_grad():
+        lin[1].running_mean.fill_(float(rank + 1))
+    bucket = pcf_dist.GradBucket(lin.parameters(), lin.buffers())
+    bucket.broadcast_parameters()
+    assert float(lin[1].running_mean[0]) == 1.0
+    with torch.no_grad():
+        lin[1].running_var.fill_(float(10 + rank))
+    bucket.sync_buffers()
+    assert float(lin[1].running_var[0]) == 10.0
+    out.put((rank, 'ok'))
+    pcf_dist.shutdown()
+
+
+def _run_two(worker):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = []
+    for _ in procs:
+        res.append(q.get(timeout=240))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return sorted(res, key=lambda t: t[0])
+
+
+@pytest.mark.timeout(300)
+def test_sync_batchnorm_statistics_and_buffers_two_ranks():
+    """pcf_fused.sync_bn_act over two gloo ranks with unequal shares == BatchNorm over the whole batch (output, input
+    gradient, running statistics; parameter gradients are rank-local parts that sum to the whole); GradBucket carries
+    buffers like DDP."""
+    assert [r[1] for r in _run_two(_sync_bn_worker)] == ['ok', 'ok']
+
+
+def _seg_cfg():
+    import pcf_model
+    c = pcf_model.Config(USE_PE=True, num_classes=5, PCONV_OPT=False, USE_CUDA_KERNEL=True)
+    pcf_model.get_default_configs(c, num_level=3, base_dim=16)
+    c.update(feat_dim=[16, 32, 48], mid_dim=[4, 4, 4], mid_dim_back=1, guided_level=0, num_heads=4,
+             resblocks=[0, 1, 1], resblocks_back=[0, 0, 0])
+    return c
+
+
+class OracleDrivenModel(torch.nn.Module):
+    """pcf_model.PointConvFormer_Segmentation's parameters and buffers, the oracle's forward."""
+
+    def __init__(self, net):
+        super().__init__()
+        self.net = net
+
+    def forward(self, feats, pcs, es, ef, ep, nrms):
+        from oracle import pcf_oracle as O
+        table = dict(self.net.named_parameters())
+        table.update(dict(self.net.named_buffers()))
+        return O.segmentation_model(O.Params(table, '', True), self.net.cfg, feats, pcs, es, ef, ep, nrms)
+
+
+def _seg_scene(seed, counts=(120, 60, 30), K=8):
+    from oracle import pcf_oracle as O
+    g = torch.Generator().manual_seed(seed)
+    pcs = [torch.rand(counts[0], 3, generator=g)]
+    nrms = [torch.nn.functional.normalize(torch.randn(counts[0], 3, generator=g), dim=-1)]
+    for c in counts[1:]:
+        sel = torch.randperm(pcs[-1].shape[0], generator=g)[:c]
+        pcs.append(pcs[-1][sel])
+        nrms.append(nrms[-1][sel])
+    knn = lambda r, q: torch.from_numpy(O.knn_bruteforce(r.numpy(), q.numpy(), K))[None]
+    es = [knn(p, p) for p in pcs]
+    ef = [knn(pcs[l], pcs[l + 1]) for l in range(len(pcs) - 1)]
+    ep = [knn(pcs[l + 1], pcs[l]) for l in range(len(pcs) - 1)]
+    feats = torch.randn(1, counts[0], 3, generator=g)
+    target = torch.randint(0, 5, (counts[0],), generator=g)
+    return feats, [p[None] for p in pcs], es, ef, ep, [n[None] for n in nrms], target
+
+
+def _seg_model():
+    import pcf_model
+    torch.manual_seed(3)
+    return pcf_model.PointConvFormer_Segmentation(_seg_cfg())
+
+
+def _seg_step(model, scene):
+    feats, pcs, es, ef, ep, nrms, target = scene
+    loss = torch.nn.functional.cross_entropy(model(feats, pcs, es, ef, ep, nrms).reshape(-1, 5), target, label_smoothing=0.2)
+    loss.backward()
+    return loss
+
+
+def _model_worker(rank, world, port, out):
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    import pcf_dist
+    import pcf_train
+    _, _, _, dev = pcf_dist.setup('gloo')
+    net = _seg_model()
+    model = pcf_dist.wrap_ddp(OracleDrivenModel(net), dev)
+    _seg_step(model, _seg_scene(pcf_dist.data_seed(200, rank)))
+    grads = {n: p.grad.numpy().copy() for n, p in net.named_parameters()}
+    # the optimiser step of the training loop on the averaged gradients: every rank ends with the same parameters
+    opt = torch.optim.AdamW(net.parameters(), lr=0.02, weight_decay=0.05)
+    pcf_train.clip_grad_norm_(opt, 10)
+    opt.step()
+    flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    both = [torch.empty_like(flat) for _ in range(world)]
+    torch.distributed.all_gather(both, flat)
+    assert torch.equal(both[0], both[1])
+    out.put((rank, grads))
+    pcf_dist.shutdown()
+
+
+@pytest.mark.timeout(300)
+def test_segmentation_model_training_step_ddp_two_ranks():
+    """One training step of the whole segmentation graph (pcf_model's parameters, the oracle's forward) under DDP over
+    two gloo ranks with rank-local scenes: the gradients every rank ends up with are the mean of the two
+    single-process gradients, and the optimiser leaves both ranks with identical parameters."""
+    res = _run_two(_model_worker)
+    want = None
+    for rank in range(2):
+        net = _seg_model()
+        _seg_step(OracleDrivenModel(net), _seg_scene(200 + rank))
+        g = {n: p.grad for n, p in net.named_parameters()}
+        want = g if want is None else {n: (want[n] + g[n]) / 2 for n in g}
+    for rank, grads in res:
+        for n, gexp in want.items():
+            torch.testing.assert_close(torch.from_numpy(grads[n]), gexp, rtol=1e-4, atol=1e-5 * max(1.0, float(gexp.abs().max())),
+                                       msg=lambda m, n=n: f'{n}: {m}')

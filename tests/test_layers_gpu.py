@@ -759,3 +759,50 @@ def test_edge_chain_rejects_what_it_does_not_cover(device):
     fx = torch.randn(1, 8, 16, device=device)
     with pytest.raises(RuntimeError, match='power of two'):
         pcf_fused.pcf_chain(vi, idx, u, fx, list(zip(lin, bns)), True)
+
+
+def test_eval_mode_backward_against_oracle(device):
+    """model.eval() followed by backward (frozen-BatchNorm fine-tuning, saliency): the fused chains need batch statistics in
+    their backward, so eval-mode forward under autograd must fall back to the per-layer kernels (running statistics) and
+    give the oracle's output, feature gradient and parameter gradients.  Under no_grad the fused inference pass stays on."""
+    import pcf_layers
+    from oracle import pcf_oracle as O
+    g = torch.Generator().manual_seed(12)
+    N, K = 384, 16
+    xyz = torch.rand(1, N, 3, generator=g)
+    nrm = torch.nn.functional.normalize(torch.randn(1, N, 3, generator=g), dim=-1)
+    feats = torch.randn(1, N, 64, generator=g)
+    idx = torch.from_numpy(O.knn_bruteforce(xyz[0].numpy(), xyz[0].numpy(), K))[None]
+    torch.manual_seed(5)
+    layer = pcf_layers.PCFLayer(64, 64, cfg(), weightnet=[12, 16], num_heads=8, guidance_feat_len=32)
+    for m in layer.modules():                        # non-trivial running statistics
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.2)
+            m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+    layer.to(device).eval()
+    d = lambda t: t.to(device)
+    assert layer._chain_layers(torch.empty(1, N, K, 12, device=device), d(idx)) is None          # autograd on: no chain
+    with torch.no_grad():
+        assert layer._chain_layers(torch.empty(1, N, K, 12, device=device), d(idx)) is not None   # inference: fused pass
+        out_ng, _ = layer(d(xyz), d(feats), d(idx), d(nrm))
+    fd = d(feats).requires_grad_(True)
+    out, _ = layer(d(xyz), fd, d(idx), d(nrm))
+    up = torch.randn(out.shape, generator=g)
+    out.backward(d(up))
+    sd = {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point() and 'running' not in k)
+          for k, v in layer.state_dict().items()}
+    fr = feats.clone().requires_grad_(True)
+    want, _ = O.pcf_layer(O.Params(sd, '', False), xyz, fr, idx, nrm, num_heads=8)
+    want.backward(up)
+    torch.testing.assert_close(out.detach().cpu(), want.detach(), **TOL)
+    torch.testing.assert_close(out_ng.cpu(), want.detach(), **TOL)
+    torch.testing.assert_close(fd.grad.cpu(), fr.grad, **TOL)
+    top = max(float(v.grad.abs().max()) for v in sd.values() if v.grad is not None)
+    for name, prm in layer.named_parameters():
+        torch.testing.assert_close(prm.grad.cpu(), sd[name].grad, rtol=1e-3, atol=1e-3 * max(1.0, top), msg=lambda m, n=name: f'{n}: {m}')
+    # a WeightNet alone (PointConv family): same rule
+    wn = pcf_layers.WeightNet(12, 16).to(device).eval()
+    x = torch.randn(1, 64, 16, 12, device=device)
+    y = wn(x)
+    y.sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in wn.parameters())

@@ -1,0 +1,144 @@
+"""GPU: the whole PointConvFormer_Segmentation graph and every block of it at the REAL widths of the four model YAMLs
+in BASELINE.json (configPCF_10cm_lite, configPCF_10cm = configPCF_5cm, configPCF_2cm_PTF2) against fixtures of the
+reference model (tests/golden/make_golden_models.py), plus whole training iterations at scene sizes of the configs.
+
+What is held to what:
+  * logits of the whole model: 1e-3 against the reference's float64 run;
+  * every block on its own (output, input gradients, every parameter gradient): 1e-3;
+  * whole-model gradients: 1e-3 widened to 4x the reference's OWN fp32-vs-fp64 deviation per tensor (1-10 % through
+    29 BatchNorm-coupled layers: no fp32 implementation, the reference included, reproduces them tighter);
+  * which kernels ran (pcf_cuda.launch_log): the matrix-core aggregates for C_mid = 16 and 4, the C_mid = 1 wave
+    kernels of the decoder, the fused edge chains.
+"""
+import pytest
+import torch
+
+import model_fixture as MF
+
+pytestmark = pytest.mark.gpu
+
+
+def _opt_key_map(net):
+    """PCONV_OPT=True parameter / buffer names -> the names the reference uses with PCONV_OPT=False
+    (layers.py:591-602: `pconv_linear_opt.linear` + `bn` versus `linear.c` + `linear.bn`)."""
+    m = {}
+    for name, mod in net.named_modules():
+        if hasattr(mod, 'pconv_linear_opt'):
+            pre = name + '.' if name else ''
+            for t in ('weight', 'bias'):
+                m[pre + 'pconv_linear_opt.linear.' + t] = pre + 'linear.c.' + t
+            if hasattr(mod, 'bn'):
+                for t in ('weight', 'bias', 'running_mean', 'running_var', 'num_batches_tracked'):
+                    m[pre + 'bn.' + t] = pre + 'linear.bn.' + t
+    return m
+
+
+def _build(g, device, opt, **over):
+    import pcf_model
+    cfg = pcf_model.Config(MF.model_cfg(g, PCONV_OPT=opt, USE_CUDA_KERNEL=True, **over))
+    net = pcf_model.PointConvFormer_Segmentation(cfg)
+    kmap = _opt_key_map(net) if opt else {}
+    ref_shapes = {kmap.get(k, k): tuple(v.shape) for k, v in net.named_parameters()}
+    assert sorted(ref_shapes) == sorted(MF.reference_parameter_names(g))
+    ref = MF.synthetic_state(ref_shapes)
+    sd = net.state_dict()
+    for k in sd:
+        if kmap.get(k, k) in ref:
+            sd[k] = ref[kmap.get(k, k)]
+    net.load_state_dict(sd, strict=True)
+    net.to(device).train()
+    for name, f in MF.drop_factors(g).items():        # the recorded DropPath keep mask of the fixture
+        mod = dict(net.named_modules())[name]
+        mod.drop_path.draw = (lambda x, f=f: x.new_full((1, 1, 1), f))
+    return cfg, net, kmap
+
+
+EXPECT_KERNELS = {
+    # fixture -> kernels that must appear in the launch log of one forward + backward
+    'lite': ['agg_fwd_mfma_kernel<4,0>', 'agg_bwd_mfma_kernel<4,0>', 'agg1_fwd_kernel', 'agg1_bwd_kernel', 'csr_gather1_kernel'],
+    '10cm': ['agg_fwd_mfma_kernel<16,0>', 'agg_bwd_mfma_kernel<16,0>', 'pconv_fwd_mfma_kernel<16>', 'pconv_bwd_mfma_kernel<16>',
+             'agg1_fwd_kernel', 'agg1_bwd_kernel', 'csr_gather1_kernel'],
+    '2cm': ['agg_fwd_mfma_kernel<16,0>', 'agg_bwd_mfma_kernel<16,0>'],
+}
+
+
+@pytest.mark.parametrize('opt', [True, False])
+@pytest.mark.parametrize('tag', MF.TAGS)
+def test_model_at_real_widths(device, tag, opt):
+    import knn_post_dataloader_utils as U
+    import pcf_cuda
+    g = MF.load(tag)
+    cfg, net, kmap = _build(g, device, opt)
+    feats, pcs, es, ef, ep, nrms = MF.inputs(g, device)
+    inv = U.compute_knn_inverse(pcs, es, ef, ep) if opt else (None, None, None)
+    pcf_cuda.launch_log(True)
+    out = net(feats, pcs, es, ef, ep, nrms, *inv)
+    torch.testing.assert_close(out.cpu(), g['out'], rtol=1e-3, atol=1e-3)
+    out.backward(g['gup'].to(device))
+    log = set(pcf_cuda.read_launch_log())
+    pcf_cuda.launch_log(False)
+    if opt:
+        missing = [k for k in EXPECT_KERNELS[tag] if k not in log]
+        assert not missing, (missing, sorted(log))
+    assert any(k.startswith('pcf_chain') for k in log), sorted(log)          # the fused edge graph of the PCFLayers
+    gin_scale = float(g['gin.features'].abs().max())
+    floor = 4.0 * float(g['nz.gin.features']) / gin_scale
+    torch.testing.assert_close(feats.grad.cpu(), g['gin.features'], rtol=1e-3 + floor, atol=(1e-3 + floor) * gin_scale)
+    bad = MF.bad_parameter_grads(((n, p.grad) for n, p in net.named_parameters()), g, kmap)
+    assert not bad, (len(bad), bad[:8])
+
+
+@pytest.mark.parametrize('opt', [True, False])
+@pytest.mark.parametrize('tag', MF.TAGS)
+def test_model_blocks_at_real_widths(device, tag, opt):
+    """Each block of the model standalone on the HIP path: 1e-3 on output, input gradients, every parameter gradient."""
+    import pcf_cuda
+    g = MF.load(tag)
+    cfg, net, kmap = _build(g, device, opt)
+    _, pcs, es, ef, ep, nrms = MF.inputs(g, device)
+    mods = dict(net.named_modules())
+    failures = []
+    for name, kind, lin, lout, cin, cout in MF.block_plan(cfg):
+        m = mods[name]
+        feats, skip, up, edges = MF.block_case(g, name, kind, lin, lout, cin, cout, device)
+        inv = {}
+        if opt:
+            n_ref = pcs[lin].shape[1]
+            a, b, c = pcf_cuda.compute_knn_inverse(edges, n_ref)
+            inv = dict(inv_neighbors=a, inv_k=b, inv_idx=c)
+        net.zero_grad(set_to_none=True)
+        if kind in ('pointconv', 'self'):
+            out, _ = m(pcs[lin], feats, edges, nrms[lin], **inv)
+        elif kind == 'down':
+            out, _ = m(pcs[lin], feats, edges, nrms[lin], pcs[lout], nrms[lout], **inv)
+        else:
+            out, _ = m(pcs[lin], feats, edges, nrms[lin], pcs[lout], nrms[lout], skip, **inv)
+        out.backward(up)
+        pre = name + '.'
+        bkmap = {k[len(pre):]: v[len(pre):] for k, v in kmap.items() if k.startswith(pre)}
+        bad = MF.block_mismatch(g, name, out, feats, skip, ((k, p.grad) for k, p in m.named_parameters()), bkmap)
+        if bad:
+            failures.append((name, bad[:4]))
+    assert not failures, (len(failures), failures[:6])
+
+
+def test_drop_path_module(device):
+    """pcf_layers.DropPath: identity in eval and at rate 0; in training one Bernoulli(keep) / keep factor per batch row
+    (timm's DropPath, which layers.py:9 imports) -- checked statistically and on the values it can take."""
+    import pcf_layers
+    dp = pcf_layers.DropPath(0.25).to(device)
+    x = torch.ones(4000, 3, 5, device=device)
+    dp.eval()
+    assert dp.draw(x) is None and dp(x) is x
+    dp.train()
+    torch.manual_seed(0)
+    y = dp(x)
+    per_row = y[:, 0, 0]
+    assert set(per_row.unique().cpu().tolist()) <= {0.0, pytest.approx(1 / 0.75)}
+    assert (y == per_row[:, None, None]).all()                      # one factor per row
+    kept = float((per_row > 0).float().mean())
+    assert abs(kept - 0.75) < 0.03, kept
+    assert pcf_layers.DropPath(0.).to(device).train().draw(x) is None
+    import pcf_model
+    c = pcf_model.Config(MF.model_cfg(MF.load('2cm'), PCONV_OPT=True, USE_CUDA_KERNEL=True))
+    assert isinstance(pcf_layers.PCFLayer(64, 64, c, [12, 16], 8).drop_path, pcf_layers.DropPath)

@@ -53,8 +53,23 @@ PCF_SHAPES = [
 ]
 
 
+ENGINES = ['default', 'lds', 'tiled']
+
+
+@pytest.fixture
+def engine(request):
+    """Run a test under one of the aggregate kernel families (pcf_hip_set_aggregate_engine): the default dispatch, the
+    LDS-tiled kernels everywhere (the cross-check of the matrix-core ones), the tiled matrix-core kernels everywhere."""
+    import pcf_cuda
+    pcf_cuda.set_aggregate_engine(request.param)
+    assert pcf_cuda.get_aggregate_engine() == request.param
+    yield request.param
+    pcf_cuda.set_aggregate_engine('default')
+
+
+@pytest.mark.parametrize('engine', ENGINES, indirect=True)
 @pytest.mark.parametrize('shape', PCF_SHAPES)
-def test_pcf_forward_backward(device, shape):
+def test_pcf_forward_backward(device, shape, engine):
     import pcf_cuda
     B, N, Nout, K, Ci, Cm, H = shape
     x, idx, guid, w, _ = _case(B, N, Nout, K, Ci, 0, Cm, H, seed=sum(shape))
@@ -83,11 +98,14 @@ PCONV_SHAPES = [
     (2, 90, 90, 16, 16, 16, 4),        # ... 10cm-lite (C_mid = 4), batch 2
     (1, 200, 200, 16, 32, 16, 4),      # three channel tiles
     (1, 150, 150, 16, 32, 0, 16),      # no appended features
+    (1, 40, 110, 16, 384, 32, 3),      # configPCF_2cm_PTF2 decoder (mid_dim_back 3), widest layer
+    (1, 90, 250, 16, 128, 16, 3),      # ... narrowest
 ]
 
 
+@pytest.mark.parametrize('engine', ENGINES, indirect=True)
 @pytest.mark.parametrize('shape', PCONV_SHAPES)
-def test_pconv_forward_backward(device, shape):
+def test_pconv_forward_backward(device, shape, engine):
     import pcf_cuda
     B, N, Nout, K, Ci, Ca, Cm = shape
     x, idx, _, w, add = _case(B, N, Nout, K, Ci, Ca, Cm, 1, seed=sum(shape))
@@ -101,6 +119,40 @@ def test_pconv_forward_backward(device, shape):
     torch.testing.assert_close(gw.cpu(), ww, **TOL)
     torch.testing.assert_close(ga.cpu(), wa, **TOL)
     torch.testing.assert_close(gx.cpu(), wx, **TOL)
+
+
+@pytest.mark.parametrize('Cm', [16, 1])
+def test_aggregate_engines_select_their_kernels(device):
+    """The engine switch really changes the kernels (launch log), and the three families agree with each other to fp32
+    rounding at the BASELINE shape (Ci = Cm = 16, H = 8, K = 16) and at C_mid = 4."""
+    import pcf_cuda
+    want = {('default', 16): ('agg_fwd_fx_mfma_kernel', 'agg_bwd_fx_mfma_kernel'),
+            ('lds', 16): ('agg_fwd_kernel<16,true,true>', 'agg_bwd_kernel<16,true,fx>'),
+            ('tiled', 16): ('agg_fwd_mfma_kernel<16,0>', 'agg_bwd_mfma_kernel<16,0>'),
+            ('default', 4): ('agg_fwd_mfma_kernel<4,0>', 'agg_bwd_mfma_kernel<4,0>'),
+            ('lds', 4): ('agg_fwd_kernel<4,true>', 'agg_bwd_kernel<4,true>')}
+    d = lambda t: t.to(device)
+    try:
+        for Cm in (16, 4):
+            x, idx, guid, w, _ = _case(1, 700, 700, 16, 16, 0, Cm, 8, seed=31 + Cm)
+            gout = torch.randn(1, 700, 16 * Cm, generator=torch.Generator().manual_seed(2))
+            res = {}
+            for eng in ENGINES:
+                if (eng, Cm) not in want:
+                    continue
+                pcf_cuda.set_aggregate_engine(eng)
+                pcf_cuda.launch_log(True)
+                out = pcf_cuda.pcf_forward(d(x), d(idx), d(guid), d(w))
+                grads = pcf_cuda.pcf_backward(d(gout), d(x), d(idx), d(guid), d(w))
+                log = pcf_cuda.read_launch_log()
+                assert log == list(want[(eng, Cm)]), (eng, Cm, log)
+                res[eng] = [out.cpu()] + [t.cpu() for t in grads]
+            for eng in res:
+                for a, b in zip(res[eng], res['default']):
+                    torch.testing.assert_close(a, b, rtol=1e-5, atol=2e-5 * float(b.abs().max()))
+    finally:
+        pcf_cuda.launch_log(False)
+        pcf_cuda.set_aggregate_engine('default')
 
 
 @pytest.mark.parametrize('Cm', [16, 1])
@@ -193,6 +245,8 @@ LIN_SHAPES = [
     (2, 70, 110, 5, 192, 32, 1, 24),      # C_mid = 1 kernels: batch 2, odd K, 48 quads per row (not a power of two)
     (1, 50, 120, 16, 384, 32, 1, 40),     # C_mid = 1, widest decoder layer: two lane passes per row
     (1, 90, 60, 16, 8, 0, 1, 12),         # C_mid = 1, two quads per row: 32 list entries per wave step
+    (1, 40, 110, 16, 384, 32, 3, 256),    # configPCF_2cm_PTF2 decoder (mid_dim_back 3): 1248 -> 256
+    (1, 90, 250, 16, 128, 16, 3, 64),     # ... 432 -> 64
 ]
 
 
