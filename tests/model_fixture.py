@@ -52,10 +52,9 @@ def drop_factors(g):
 
 
 def bad_parameter_grads(named_grads, g, kmap=None, rtol=1e-3, atol=1e-3, noise_mult=4.0):
-    """Whole-model parameter gradients against the reference's float64 run.  named_grads: (name, grad) under the BUILD's
-    names; kmap maps them to the reference's.  Bound per tensor: rtol / atol * max(1, |ref|_max), widened to
-    noise_mult x the reference's own fp32-vs-fp64 deviation of that tensor (`nz.*`: 1-10 % of the scale through 29
-    BatchNorm-coupled layers -- see tests/golden/make_golden_models.py).  -> list of offenders."""
+    """Whole-model parameter gradients against the reference's float64 run, tensor by tensor, with the bound
+    rtol / atol * max(1, |ref|_max) widened by noise_mult x the reference's own fp32-vs-fp64 deviation of that tensor
+    (`nz.*`).  -> list of offenders.  (The CPU test uses it with noise_mult = 0 for the float64 oracle.)"""
     kmap = kmap or {}
     seen, bad = 0, []
     for name, grad in named_grads:
@@ -68,6 +67,28 @@ def bad_parameter_grads(named_grads, g, kmap=None, rtol=1e-3, atol=1e-3, noise_m
         seen += 1
     assert seen == len(reference_parameter_names(g)), (seen, len(reference_parameter_names(g)))
     return bad
+
+
+def gradient_noise_ratios(named_grads, g, kmap=None, tol=1e-3):
+    """Whole-model parameter gradients of an fp32 implementation, measured in units of the reference's OWN fp32 rounding
+    deviation: per tensor max|got - truth| / max(nz, tol * scale), where truth = the reference in float64, nz = the
+    deviation of the reference's float32 run from it, scale = max(1, |truth|_max).  A faithful fp32 implementation has
+    ratios distributed like the reference's own (1 by construction): ~1 in the median, a tail of a few."""
+    kmap = kmap or {}
+    ratios = {}
+    for name, grad in named_grads:
+        ref_name = kmap.get(name, name)
+        assert grad is not None and torch.isfinite(grad).all(), name
+        flat = grad.detach().reshape(-1).float().cpu()
+        if 'gsd.' + ref_name in g:
+            ref, got = g['gsd.' + ref_name].reshape(-1), flat
+        else:
+            ref = g['gsmp.' + ref_name]
+            got = flat[::flat.numel() // GRAD_SAMPLE][:GRAD_SAMPLE]
+        scale = max(1.0, float(ref.abs().max()))
+        ratios[name] = float((got - ref).abs().max()) / max(float(g['nz.' + ref_name]), tol * scale)
+    assert len(ratios) == len(reference_parameter_names(g))
+    return ratios
 
 
 def block_plan(cfg):

@@ -25,7 +25,7 @@ def _grads(net, cfg, batch, edges, crit):
     pred = net(features, pointclouds, es, ef, ep, norms, *inv)
     loss = crit(pred.reshape(-1, cfg.num_classes), target)
     loss.backward()
-    return float(loss), torch.cat([p.grad.reshape(-1) for p in net.parameters()]).double()
+    return float(loss.detach()), torch.cat([p.grad.reshape(-1) for p in net.parameters()]).double()
 
 
 @pytest.mark.parametrize('name,scenes,points', [('configPCF_10cm_lite', 4, 40000), ('configPCF_5cm', 1, 150000),
@@ -41,7 +41,7 @@ def test_training_iteration(device, name, scenes, points):
     batch = _batch(cfg, device, scenes, points, seed=4000)
     features, pointclouds, target, norms, stored = batch
     n0 = sum(stored[0])
-    assert abs(n0 - scenes * points) < 0.1 * scenes * points and len(pointclouds) == 5
+    assert abs(n0 - scenes * points) < 0.15 * scenes * points and len(pointclouds) == 5
     edges = pcf_train.build_edges(cfg, pointclouds, stored)
 
     # ---- kNN and CSR tables of this batch against the C oracle: coarse levels whole, level 0 on a sub-sample ----
