@@ -102,12 +102,7 @@ def cpu_baseline(state_dict, xyz, nrm, feats, idx, iters=3):
             f'iterations, median {med * 1e3:.0f} ms; oracle/pcf_oracle.py:pcf_layer on torch CPU'}
 
 
-LITE_YAML = dict(   # configs/configPCF_10cm_lite.yaml (model + training keys on the GPU path)
-    BATCH_NORM=True, USE_XYZ=True, USE_PE=True, point_dim=3, num_level=5, grid_size=[0.1, 0.2, 0.4, 0.8, 1.6],
-    base_dim=64, feat_dim=[64, 128, 192, 256, 384], mid_dim=[4, 4, 4, 4, 4], mid_dim_back=1, guided_level=0,
-    num_heads=8, resblocks=[0, 3, 3, 3, 3], resblocks_back=[0, 0, 0, 0, 0], K_self=[16] * 5, K_forward=[16] * 5,
-    K_propagate=[16] * 5, num_classes=20, label_smoothing=0.2, learning_rate=0.02, adamw_decay=0.05,
-    ignore_label=-100, drop_path_rate=0., dropout_rate=0., dropout_fc=0., layer_norm_guidance=False)
+LITE_GRID = [0.1, 0.2, 0.4, 0.8, 1.6]        # configs/configPCF_10cm_lite.yaml grid_size (subsample workload)
 
 
 def bench_train(args):
@@ -118,9 +113,11 @@ def bench_train(args):
     rank, world, local_rank, dev = pcf_dist.setup('nccl')
     import pcf_model
     import pcf_train
-    cfg = pcf_model.Config(LITE_YAML)
-    pcf_model.get_default_configs(cfg, num_level=cfg.num_level, base_dim=cfg.base_dim)
-    cfg.PCONV_OPT, cfg.USE_CUDA_KERNEL = True, True
+    cfg = pcf_train.baseline_config(args.model)
+    if args.points is None:
+        args.points = cfg.scene_points
+    if args.scenes is None:
+        args.scenes = cfg.scenes
     torch.manual_seed(1)
     net = pcf_model.PointConvFormer_Segmentation(cfg).to(dev).train()
     model = pcf_dist.wrap_ddp(net, dev)
@@ -147,12 +144,12 @@ def bench_train(args):
     elapsed = pcf_dist.max_over_ranks(time.perf_counter() - t0, dev)
     if rank == 0:
         print(json.dumps({
-            'metric': 'ScanNet-10cm (lite) train iters/sec, synthetic scenes', 'value': round(args.steps / elapsed, 3),
+            'metric': f'{args.model} train iters/sec, synthetic scenes', 'value': round(args.steps / elapsed, 3),
             'unit': 'iters/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'points_per_s': round(world * n_pts * args.steps / elapsed, 1), 'final_loss': round(float(loss), 4),
-            'config': {'workload': f'configPCF_10cm_lite model ({sum(p.numel() for p in net.parameters())} params), '
+            'config': {'workload': f'{args.model} model ({sum(p.numel() for p in net.parameters())} params), '
                                    f'{args.scenes} scenes x ~{args.points} points per GPU per iteration '
                                    f'({n_pts} level-0 points, levels {pool[0][4]}), kNN + CSR + fwd + bwd + AdamW',
                        'parallelism': f'dp{world}', 'sync_bn': False}}), flush=True)
@@ -170,7 +167,7 @@ def bench_subsample(args):
     import knn_post_dataloader_utils as U
     import pcf_cuda
     import pcf_train
-    grid = LITE_YAML['grid_size']
+    grid = LITE_GRID
     scenes = [pcf_train.synthetic_scene(args.points, grid, seed=1000 * (rank + 1) + i, device=dev) for i in range(args.scenes)]
     xyz = torch.cat([s['xyz'] for s in scenes])
     nrm = torch.cat([s['nrm'] for s in scenes])
@@ -258,7 +255,10 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--points', type=int, default=None)
     ap.add_argument('--workload', choices=['layer', 'train', 'subsample'], default='layer')
-    ap.add_argument('--scenes', type=int, default=4, help='scenes per GPU per iteration (train workload)')
+    ap.add_argument('--scenes', type=int, default=None, help='scenes per GPU per iteration (train / subsample workloads)')
+    ap.add_argument('--model', default='configPCF_10cm_lite',
+                    choices=['configPCF_10cm_lite', 'configPCF_10cm', 'configPCF_5cm', 'configPCF_2cm_PTF2'],
+                    help='model YAML of the train workload (pcf_train.BASELINE_CONFIGS)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true',
                     help='time eager steps (default on 1 GPU: HIP-graph replay of the step when capture succeeds; '
@@ -270,10 +270,12 @@ def main():
     ap.add_argument('--deterministic', action='store_true',
                     help='grad_x by CSR gather-reduce (bitwise reproducible) instead of float atomics')
     args = ap.parse_args()
-    if args.points is None:
-        args.points = N_POINTS if args.workload == 'layer' else 40000
     if args.workload == 'train':
         return bench_train(args)
+    if args.points is None:
+        args.points = N_POINTS if args.workload == 'layer' else 40000
+    if args.scenes is None:
+        args.scenes = 4
     if args.workload == 'subsample':
         return bench_subsample(args)
 

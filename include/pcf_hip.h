@@ -57,6 +57,11 @@ size_t pcf_hip_launch_log_read(char* buf, size_t capacity);
  * the initial value. */
 int pcf_hip_set_aggregate_engine(int engine);
 int pcf_hip_get_aggregate_engine(void);
+/* Last pass of the fused edge-graph backward (pcf_hip_pcf_chain_backward / pcf_hip_weightnet_chain_backward): 1 = the
+ * operands of its outer products are turned through LDS tiles (default: faster by 5 % at 1.28 M edges), 0 = they are
+ * produced in registers in the transposed lane layout (no LDS traffic, more vector-memory instructions).  Process-wide;
+ * PCF_CHAIN_BWD_LDS=0 sets the initial value. */
+int pcf_hip_set_chain_backward_engine(int lds_transposes);
 
 /* ---- guided aggregate (PCF) ------------------------------------------------------------------
  * replaces pcf_cuda.pcf_forward / pcf_backward        (pcf_cuda.cpp:10-11, pcf.h:38-66,

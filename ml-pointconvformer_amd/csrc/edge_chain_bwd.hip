@@ -29,6 +29,8 @@
 // fragment A[i = c][k <-> o = 4k + s], so a dz accumulator is again directly the B operand.  The 13 weight
 // fragments (8 forward, 5 transposed) and the BatchNorm constants live in LDS, not in registers.
 #include <algorithm>
+#include <atomic>
+#include <cstdlib>
 
 #include "edge_chain.h"
 
@@ -423,8 +425,240 @@ __device__ __forceinline__ void weightnet_branch(const ChainBwdArgs& a, const fl
     }
 }
 
+// ---- pass 3 without LDS transposes ---------------------------------------------------------------------------
+// The outer products dW += sum_e dz[o][e] * in[c][e] contract over EDGES, so both operands are wanted with the channel on
+// the low lane bits and the edge on (lane >> 4, register) -- "layout T" -- while the layer products keep the edge on
+// the low lane bits and the channel on (lane >> 4, register) -- "layout E".  Transposing six 16x16 tiles per 16 edges
+// through LDS (one b128 store + eight b32 reads per operand) made this pass LDS-bound (87 us of LDS against 54 us of
+// matrix work at 1.28 M edges).  The matrix core transposes for free: with the activation as the A operand and
+// the weight fragment as the B operand, D[i = edge][j = channel] = sum_c Y[edge][c] W[channel][c] lands in layout T
+// (the SAME fragment registers serve both roles, since lane (p, g) step s holds W[p][4g + s] either way).  So
+//   * everything that only feeds outer products or element-wise masks is PRODUCED in layout T (mlp_conv / w1 recompute,
+//     the masked gradients g_pe / g_a1),
+//   * what is read from memory is read in both layouts (the second read hits the cache lines of the first),
+//   * the few tensors needed both ways (dq, dz of w2) are computed twice from those loads (8 fused multiply-adds),
+//   * per-channel BatchNorm constants of layout T are one scalar per lane, kept in registers.
+// Neighbourhood sums of the key subtraction in layout T run over registers and over lane bits 4-5: v_permlane16_swap /
+// v_permlane32_swap (gfx950) of a register with itself give the two butterfly partners without touching LDS.
+__device__ __forceinline__ float xor16_sum(float v) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor32_sum(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// lane i <- lane i + 8 of its row of 16 (zero beyond the row)
+__device__ __forceinline__ float row_shl8(float v) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x108, 0xf, 0xf, true));
+}
+// sum over the aligned group of K (power of two <= 16) consecutive lanes of a row, in every lane of the group: DPP only
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float group_sum_dpp(float v, int K) {
+    if (K >= 2) v += dpp_mov<0xB1>(v);          // quad_perm [1,0,3,2]
+    if (K >= 4) v += dpp_mov<0x4E>(v);          // quad_perm [2,3,0,1]
+    if (K >= 8) v += dpp_mov<0x141>(v);         // row_half_mirror: the other quad of the half row
+    if (K >= 16) v += dpp_mov<0x140>(v);        // row_mirror: the other half row
+    return v;
+}
+// activation (layout E) as the A operand: result in layout T
+__device__ __forceinline__ f32x4 mm_t(const float4* wl, int frag, int lane, f32x4 operand, f32x4 acc) {
+    const f32x4 w = to_v4(wl[frag * WAVE + lane]);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = PCF_MFMA(operand[s], w[s], acc);
+    return acc;
+}
+__device__ __forceinline__ f32x4 outer_t(f32x4 dz, f32x4 in, f32x4 acc) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = PCF_MFMA(dz[s], in[s], acc);
+    return acc;
+}
+// two [E, 8] tensors of one tile in layout T with four loads: lanes p < 8 read channel p of `lo`, lanes p >= 8 channel
+// p - 8 of `hi`; a row shift brings the second to the lanes of the first.  Valid in lanes p < 8, zero elsewhere.
+__device__ __forceinline__ void load_pair_t(const float* lo, const float* hi, long long t, int p, int g, f32x4& vlo, f32x4& vhi) {
+    const float* src = (p < 8 ? lo : hi) + (size_t)(t * 16 + 4 * g) * CH + (p & 7);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float v = src[r * CH];
+        vhi[r] = row_shl8(v);
+        vlo[r] = p < 8 ? v : 0.f;
+    }
+}
+// VI' = (VI, 1) of one tile in layout T (channel 12 is always padding, cv <= 12)
+__device__ __forceinline__ f32x4 load_x1_t(const ChainArgs& f, long long t, int p, int g) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (p < f.cv) {
+        const float* q = f.vi + (size_t)(t * 16 + 4 * g) * f.cv + p;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = q[r * f.cv];
+    } else if (p == 12) {
+        v = f32x4{1.f, 1.f, 1.f, 1.f};
+    }
+    return v;
+}
+__device__ __forceinline__ f32x4 relu_bn_t(f32x4 acc, float sc, float sh) {
+    return f32x4{fmaxf(acc[0] * sc + sh, 0.f), fmaxf(acc[1] * sc + sh, 0.f), fmaxf(acc[2] * sc + sh, 0.f), fmaxf(acc[3] * sc + sh, 0.f)};
+}
+__device__ __forceinline__ float sum4(f32x4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
+// per-channel sums of layout T live one per lane (channel p): fold lane bits 4-5, lane g == 0 writes
+__device__ __forceinline__ void put_sums_t(float (*rw)[3][2][16], int wave, int q, int p, int g, float v1, float v2) {
+    v1 = xor32_sum(xor16_sum(v1));
+    v2 = xor32_sum(xor16_sum(v2));
+    if (g == 0) { rw[wave][q][0][p] = v1; rw[wave][q][1][p] = v2; }
+}
+
+__device__ __forceinline__ void guidance_branch3_t(const ChainBwdArgs& a, const float (*cf)[NCONST][16], const float4* wl,
+                                                   float* red, float* red_s, long long t0, long long tstride) {
+    const ChainArgs& f = a.f;
+    const int lane = lane_id(), wave = wave_id(), p = lane & 15, g = lane >> 4;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const long long ntiles = f.E / 16;
+    const TileIO io{a, p, g, ntiles};
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    f32x4 accw[5] = {zero4, zero4, zero4, zero4, zero4};          // pe lo, pe hi, g1 (in lo), g1 (in hi), VI' (x) VI'
+    const bool first = (p & (f.K - 1)) == 0;
+    // layout T constants: channel p of mlp_conv lo / hi, channel p of g1
+    const float sc_pe0 = cf[S_PE0][K_SC][p], sh_pe0 = cf[S_PE0][K_SH][p], sc_pe1 = cf[S_PE1][K_SC][p], sh_pe1 = cf[S_PE1][K_SH][p];
+    const float sc_g1 = cf[S_G1][K_SC][p], d0_g1 = cf[S_G1][K_D0][p], d1_g1 = cf[S_G1][K_D1][p];
+    BatchWalk walk;
+    walk.init(f.rows_per_batch);
+    for (long long t = t0; t < ntiles; t += tstride) {
+        asm volatile("" ::: "memory");          // LDS-resident weights / constants are re-read per tile, not hoisted into VGPRs
+        // loads in the order of their use: the VI row first (the mlp_conv recompute runs while the others land)
+        const f32x4 x = io.load_x(t);
+        const f32x4 x1t = load_x1_t(f, t, p, g);
+        const f32x4 ac_h1 = io.load_grad(a.h1_acc, t, CH);
+        const f32x4 g_h1 = io.load_grad(a.gh1, t, CH);
+        f32x4 g_h1t, ac_h1t;
+        load_pair_t(a.gh1, a.h1_acc, t, p, g, g_h1t, ac_h1t);
+        // du rows of the four edges 4g..4g+3 this lane holds in layout T
+        int tgt[4];
+        {
+            (void)walk.batch_of(t * 16, 0);              // advances the walk to this tile (wave-uniform)
+            const int e_rel = (int)(walk.next_start - t * 16);                          // first edge of the next batch, tile-relative
+            const longlong2* ib = reinterpret_cast<const longlong2*>(f.idx + t * 16 + 4 * g);
+            const longlong2 j01 = ib[0], j23 = ib[1];
+            const long long jj[4] = {j01.x, j01.y, j23.x, j23.y};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int batch = walk.b + (4 * g + r >= e_rel ? 1 : 0);
+                tgt[r] = (jj[r] >= 0 && jj[r] < f.N) ? batch * f.N + (int)jj[r] : -1;
+            }
+        }
+        // mlp_conv recomputed straight into layout T
+        const f32x4 ac_pe0 = mm_t(wl, 0, lane, x, zero4);
+        const f32x4 ac_pe1 = mm_t(wl, 1, lane, x, zero4);
+        const f32x4 y_pe0 = relu_bn_t(ac_pe0, sc_pe0, sh_pe0);
+        const f32x4 y_pe1 = relu_bn_t(ac_pe1, sc_pe1, sh_pe1);
+        // dz of g1 in both layouts; z[k] = q[k] - q[key] + b  =>  dq[k] = dz[k] - [k is the key] * (sum over the neighbourhood)
+        f32x4 dq = bn_dz(g_h1, ac_h1, cf[S_G1], g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float tot = group_sum_dpp(dq[r], f.K);
+            if (first) dq[r] -= tot;
+        }
+        f32x4 dqt = g_h1t * sc_g1 + (ac_h1t * d1_g1 + d0_g1);
+        if (p >= CH) dqt = zero4;
+        if (f.K >= 4) {
+            float tot = sum4(dqt);
+            if (f.K >= 8) tot = xor16_sum(tot);
+            if (f.K >= 16) tot = xor32_sum(tot);
+            if (((4 * g) & (f.K - 1)) == 0) dqt[0] -= tot;
+        } else if (f.K == 2) {
+            const float t01 = dqt[0] + dqt[1], t23 = dqt[2] + dqt[3];
+            dqt[0] -= t01; dqt[2] -= t23;
+        } else {
+            dqt = zero4;                                 // K = 1: every edge is its own key
+        }
+        // gradient of the gathered term: lanes p = 0..7 cover the 8 consecutive channels of one row of du
+        if (p < CH) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+            {
+#ifndef PCF_EXPERIMENT_NO_DU
+                if (tgt[r] >= 0) atomicAdd(a.du + (size_t)(unsigned)tgt[r] * CH + p, dqt[r]);
+#endif
+            }
+        }
+        accw[2] = outer_t(dqt, y_pe0, accw[2]);
+        accw[3] = outer_t(dqt, y_pe1, accw[3]);
+        const f32x4 g_pe0 = mask_pos(mm_t(wl, 10, lane, dq, zero4), y_pe0);
+        const f32x4 g_pe1 = mask_pos(mm_t(wl, 11, lane, dq, zero4), y_pe1);
+        s1[0] += sum4(g_pe0); s2[0] += sum4(g_pe0 * ac_pe0);
+        s1[1] += sum4(g_pe1); s2[1] += sum4(g_pe1 * ac_pe1);
+        // moments for the dW of mlp_conv: sum g (x) VI' (two tiles) and sum VI' (x) VI'
+        accw[0] = outer_t(g_pe0, x1t, accw[0]);
+        accw[1] = outer_t(g_pe1, x1t, accw[1]);
+        accw[4] = outer_t(x1t, x1t, accw[4]);
+    }
+    // tiles: 0, 1 sum g_pe (x) VI' | 3, 4 dW of g1 | 6 sum VI' (x) VI'
+    const int tiles[5] = {0, 1, 3, 4, 6};
+    for (int wv = 0; wv < NWAVE; ++wv) {        // wave order: deterministic
+        if (wave == wv) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[tiles[i] * 256 + (4 * g + r) * 16 + p] += accw[i][r];
+        }
+        __syncthreads();
+    }
+    float (*rw)[3][2][16] = reinterpret_cast<float (*)[3][2][16]>(red_s);
+    put_sums_t(rw, wave, 0, p, g, s1[0], s2[0]);
+    put_sums_t(rw, wave, 1, p, g, s1[1], s2[1]);
+}
+
+__device__ __forceinline__ void weightnet_branch3_t(const ChainBwdArgs& a, const float (*cf)[NCONST][16], const float4* wl,
+                                                    float* red, float* red_s, long long t0, long long tstride) {
+    const ChainArgs& f = a.f;
+    const int lane = lane_id(), wave = wave_id(), p = lane & 15, g = lane >> 4;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const long long ntiles = f.E / 16;
+    const TileIO io{a, p, g, ntiles};
+    float s1 = 0.f, s2 = 0.f;
+    f32x4 accw[3] = {zero4, zero4, zero4};                        // w1 moment, dW of w2, VI' (x) VI' (wn_only)
+    const float sc_w1 = cf[S_W1][K_SC][p], sh_w1 = cf[S_W1][K_SH][p];
+    const float sc_w2 = cf[S_W2][K_SC][p], d0_w2 = cf[S_W2][K_D0][p], d1_w2 = cf[S_W2][K_D1][p];
+    for (long long t = t0; t < ntiles; t += tstride) {
+        asm volatile("" ::: "memory");
+        const f32x4 ac_a2 = io.load_grad(a.a2_acc, t, CH);
+        const f32x4 g_a2 = io.load_grad(a.ga2, t, CH);
+        const f32x4 x = io.load_x(t);
+        f32x4 g_a2t, ac_a2t;
+        load_pair_t(a.ga2, a.a2_acc, t, p, g, g_a2t, ac_a2t);
+        const f32x4 x1t = load_x1_t(f, t, p, g);
+        const f32x4 ac_a1 = mm_t(wl, 2, lane, x, zero4);
+        const f32x4 y_a1 = relu_bn_t(ac_a1, sc_w1, sh_w1);
+        const f32x4 dz_a2 = bn_dz(g_a2, ac_a2, cf[S_W2], g);
+        f32x4 dz_a2t = g_a2t * sc_w2 + (ac_a2t * d1_w2 + d0_w2);
+        if (p >= CH) dz_a2t = zero4;
+        accw[1] = outer_t(dz_a2t, y_a1, accw[1]);
+        const f32x4 g_a1 = mask_pos(mm_t(wl, 12, lane, dz_a2, zero4), y_a1);
+        s1 += sum4(g_a1); s2 += sum4(g_a1 * ac_a1);
+        accw[0] = outer_t(g_a1, x1t, accw[0]);
+        if (a.wn_only) accw[2] = outer_t(x1t, x1t, accw[2]);     // no guidance workgroups
+    }
+    const int tiles[3] = {2, 5, 6};         // 2: sum g_a1 (x) VI' | 5: dW of w2 | 6: sum VI' (x) VI' (wn_only)
+    for (int wv = 0; wv < NWAVE; ++wv) {
+        if (wave == wv) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (i < 2 || a.wn_only) red[tiles[i] * 256 + (4 * g + r) * 16 + p] += accw[i][r];
+        }
+        __syncthreads();
+    }
+    float (*rw)[3][2][16] = reinterpret_cast<float (*)[3][2][16]>(red_s);
+    put_sums_t(rw, wave, 2, p, g, s1, s2);
+}
+
 // workgroup b of the launch: branch and rank among the workgroups of its branch; NG of every 8 workgroups take
 // the guidance branch (SplitOf, chosen by measurement)
+#ifndef PCF_NG3T
+#define PCF_NG3T 5      // guidance share (of 8 workgroups) of the register-layout pass 3, by measurement
+#endif
 template <int NG> __device__ __host__ inline bool is_guidance_block(int b) { return (b & 7) < NG; }
 template <int NG> __device__ __host__ inline int branch_rank(int b) {
     return is_guidance_block<NG>(b) ? (b >> 3) * NG + (b & 7) : (b >> 3) * (8 - NG) + (b & 7) - NG;
@@ -435,17 +669,19 @@ template <int NG> __host__ inline int branch_blocks(int grid, bool guidance) {  
 // matrix instructions per tile, guidance : WeightNet = 4 : 4 (pass 1), 12 : 12 (pass 2), 36 : 16 (pass 3).
 // Measured: passes 1-2 do not care between 4 and 6 of 8 (they are closer to the memory side); pass 3 took 196 us
 // with 6 of 8, 229 us with 5, 358 us with 7 (before the 128-VGPR bound, which brings 6 of 8 to 147 us).
-template <int LEVEL> struct SplitOf { static constexpr int NG = LEVEL == 3 ? 6 : 5; };
+template <int LEVEL, bool REGT = false> struct SplitOf { static constexpr int NG = LEVEL == 3 ? (REGT ? PCF_NG3T : 6) : 5; };
 
 // at least 4 waves per SIMD (<= 128 VGPRs): the last pass lands on 132 without the bound and runs 196 us instead of 147
-template <int LEVEL>
+// REGT (pass 3 only): operands of the outer products produced in registers in the transposed layout (above) instead of
+// being turned through LDS tiles; the LDS form stays as the cross-check (pcf_hip_set_chain_backward_engine).
+template <int LEVEL, bool REGT = false>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) void pcf_chain_bwd_kernel(const ChainBwdArgs a, int grid8) {
     __shared__ __align__(16) float cf[NSLOT][NCONST][16];
     __shared__ float4 wl[NFRAG * WAVE];
     __shared__ float red[LEVEL == 3 ? NDW * 256 : 1];          // dW / moment tiles of the last pass
     __shared__ float red_s[NWAVE * 96];                         // per-channel sums of the pass
     __shared__ float red_top[LEVEL == 2 ? 2 * 256 : 1];
-    __shared__ __align__(16) float tbuf[LEVEL == 3 ? NWAVE * 3 * 16 * TT : (LEVEL == 2 ? NWAVE * 2 * 16 * TT : 4)];
+    __shared__ __align__(16) float tbuf[REGT ? 4 : LEVEL == 3 ? NWAVE * 3 * 16 * TT : (LEVEL == 2 ? NWAVE * 2 * 16 * TT : 4)];
     __shared__ int gi[NWAVE][16];
     stage_consts(a, cf, LEVEL);
     stage_weights(a, wl);
@@ -457,9 +693,14 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) v
     __syncthreads();
     const int wave = wave_id();
     float* tb = LEVEL == 3 ? tbuf + wave * 3 * 16 * TT : (LEVEL == 2 ? tbuf + wave * 2 * 16 * TT : tbuf);
-    constexpr int NG = SplitOf<LEVEL>::NG;
+    constexpr int NG = SplitOf<LEVEL, REGT>::NG;
     const int rank = branch_rank<NG>(blockIdx.x);
-    if (a.wn_only)
+    if (REGT && LEVEL == 3) {
+        if (a.wn_only) weightnet_branch3_t(a, cf, wl, red, red_s, (long long)blockIdx.x * NWAVE + wave, (long long)gridDim.x * NWAVE);
+        else if (is_guidance_block<NG>(blockIdx.x))
+            guidance_branch3_t(a, cf, wl, red, red_s, (long long)rank * NWAVE + wave, (long long)grid8 * NG * NWAVE);
+        else weightnet_branch3_t(a, cf, wl, red, red_s, (long long)rank * NWAVE + wave, (long long)grid8 * (8 - NG) * NWAVE);
+    } else if (a.wn_only)
         weightnet_branch<LEVEL>(a, cf, wl, red, red_s, red_top, tb, (long long)blockIdx.x * NWAVE + wave,
                                 (long long)gridDim.x * NWAVE);
     else if (is_guidance_block<NG>(blockIdx.x))
@@ -646,6 +887,23 @@ __global__ __launch_bounds__(BLOCK) void chain_bwd_combine_kernel(const BwdCombi
 
 }  // namespace pcf
 
+// Pass 3 of the fused backward: 1 = outer-product operands turned through LDS tiles (default), 0 = produced in registers
+// in the transposed lane layout.  Measured at 1.28 M edges (profiles/r02_pass3_engines.txt): the register form takes the
+// LDS pipe from 87 to 9 us per launch -- below the 54 us of matrix work -- but its 19 vector-memory instructions per tile
+// (the second, strided read of every operand) against 8 leave the four resident waves waiting on memory: 152 us against
+// 145 us per launch.  It stays selectable (PCF_CHAIN_BWD_LDS=0 or pcf_hip_set_chain_backward_engine(0)) and is held to the
+// LDS form by the tests.
+static std::atomic<int> g_chain_bwd_lds{-1};
+static bool chain_bwd_lds_transposes() {
+    int v = g_chain_bwd_lds.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv("PCF_CHAIN_BWD_LDS");
+        v = (e && e[0] == '0') ? 0 : 1;
+        g_chain_bwd_lds.store(v, std::memory_order_relaxed);
+    }
+    return v == 1;
+}
+
 static int chain_backward_impl(bool wn_only, const float* vi, const int64_t* idx, const float* h1_acc, const float* a2_acc,
                                const float* dscore, const float* dw, long long E, long long rows_per_batch, int N, int K, int cv, int g, int heads, int cm,
                                const float* const* W, const float* const* b, const float* const* gamma,
@@ -723,8 +981,13 @@ static int chain_backward_impl(bool wn_only, const float* vi, const int64_t* idx
         hipLaunchKernelGGL(chain_bwd_finalize_kernel, dim3(12), dim3(1024), 0, s, fa);
         if (int e = check_launch("pcf_chain_backward finalize")) return e;
     }
-    hipLaunchKernelGGL(pcf_chain_bwd_kernel<3>, dim3(grid), dim3(BLOCK), 0, s, a, grid / 8);
-    if (int e = check_launch("pcf_chain_backward final pass")) return e;
+    if (chain_bwd_lds_transposes()) {
+        hipLaunchKernelGGL((pcf_chain_bwd_kernel<3, false>), dim3(grid), dim3(BLOCK), 0, s, a, grid / 8);
+        if (int e = check_launch("pcf_chain_bwd_kernel<3> (LDS transposes)")) return e;
+    } else {
+        hipLaunchKernelGGL((pcf_chain_bwd_kernel<3, true>), dim3(grid), dim3(BLOCK), 0, s, a, grid / 8);
+        if (int e = check_launch("pcf_chain_bwd_kernel<3> (register layouts)")) return e;
+    }
     BwdReduceArgs ra{a.part, a.part_top, a.part_sums, grid, redbuf};
     hipLaunchKernelGGL(chain_bwd_reduce_kernel, dim3((RED_TOTAL + 63) / 64), dim3(1024), 0, s, ra);
     BwdCombineArgs ca{};
@@ -739,6 +1002,13 @@ static int chain_backward_impl(bool wn_only, const float* vi, const int64_t* idx
 
 
 extern "C" {
+
+int pcf_hip_set_chain_backward_engine(int lds_transposes) {
+    if (lds_transposes != 0 && lds_transposes != 1)
+        return pcf::fail(PCF_E_BADARG, "set_chain_backward_engine: 0 (register layouts) or 1 (LDS transposes), got %d", lds_transposes);
+    g_chain_bwd_lds.store(lds_transposes, std::memory_order_relaxed);
+    return pcf::ok();
+}
 
 size_t pcf_hip_pcf_chain_backward_workspace_bytes(long long E) {
     // per-workgroup partials of passes 1-4, the 12 x 64 per-channel means, and the two [E, 8] gradients pass 2 hands

@@ -88,7 +88,15 @@ _log_read = _sig('pcf_hip_launch_log_read', [ctypes.c_char_p, _Z], _Z)
 _set_engine = _sig('pcf_hip_set_aggregate_engine', [_I])
 _get_engine = _sig('pcf_hip_get_aggregate_engine', [])
 
+_set_chain_bwd_engine = _sig('pcf_hip_set_chain_backward_engine', [_I])
+
 AGG_ENGINES = {'default': 0, 'lds': 1, 'tiled': 2}
+
+
+def set_chain_backward_engine(lds_transposes: bool):
+    """Last pass of the fused edge-graph backward: LDS transposes (True, default) or register layouts (False)."""
+    if _set_chain_bwd_engine(1 if lds_transposes else 0) != 0:
+        raise RuntimeError(_last_error().decode())
 
 
 def library_path() -> str:

@@ -806,3 +806,43 @@ def test_eval_mode_backward_against_oracle(device):
     y = wn(x)
     y.sum().backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in wn.parameters())
+
+
+@pytest.mark.parametrize('K,N', [(16, 3000), (8, 2048), (4, 1000), (2, 512), (1, 256)])
+def test_fused_chain_backward_register_layouts_against_lds_transposes(device, K, N):
+    """Pass 3 of the fused edge-graph backward with the outer-product operands produced in registers (transposed lane
+    layout, matrix-core operand roles swapped) against the default form that turns them through LDS tiles
+    (pcf_cuda.set_chain_backward_engine): feature gradient, du path and all 24 parameter gradients of a PCFLayer, for
+    every neighbourhood size the key subtraction distinguishes."""
+    import pcf_cuda
+    import pcf_layers
+    g = torch.Generator().manual_seed(100 + K)
+    xyz = torch.rand(2, N, 3, generator=g).to(device)
+    nrm = torch.nn.functional.normalize(torch.randn(2, N, 3, generator=g), dim=-1).to(device)
+    feats = torch.randn(2, N, 64, generator=g).to(device)
+    idx = torch.randint(0, N, (2, N, K), generator=g)
+    if K > 1:
+        idx[:, :, 0] = torch.arange(N)                  # self first (K = 1 with the self edge alone: an all-zero VI descriptor)
+    idx = idx.to(device)
+    torch.manual_seed(3)
+    layer = pcf_layers.PCFLayer(64, 64, cfg(), weightnet=[12, 16], num_heads=8, guidance_feat_len=32).to(device).train()
+    assert layer._chain_layers(torch.empty(2, N, K, 12, device=device), idx) is not None
+    up = torch.randn(2, N, 64, generator=g).to(device)
+    res = {}
+    try:
+        for lds in (False, True):
+            pcf_cuda.set_chain_backward_engine(lds)
+            layer.zero_grad(set_to_none=True)
+            f = feats.clone().requires_grad_(True)
+            pcf_cuda.launch_log(True)
+            out, _ = layer(xyz, f, idx, nrm)
+            out.backward(up)
+            log = pcf_cuda.read_launch_log()
+            assert any(('LDS transposes' if lds else 'register layouts') in k for k in log), log
+            res[lds] = [f.grad.clone()] + [p.grad.clone() for p in layer.parameters()]
+    finally:
+        pcf_cuda.launch_log(False)
+        pcf_cuda.set_chain_backward_engine(True)
+    names = ['feats'] + [n for n, _ in layer.named_parameters()]
+    for n, a, b in zip(names, res[False], res[True]):
+        torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-4 * max(1.0, float(b.abs().max())), msg=lambda m, n=n: f'{n}: {m}')
