@@ -63,6 +63,46 @@ int pcf_hip_get_aggregate_engine(void);
  * PCF_CHAIN_BWD_LDS=0 sets the initial value. */
 int pcf_hip_set_chain_backward_engine(int lds_transposes);
 
+/* ---- point-level Linear + BatchNorm (+ activation) chains --------------------------------------------------------
+ * replaces layer_utils.Linear_BN / UnaryBlock (layer_utils.py:241-315) where a PCFLayer strings them together
+ * (layers.py:335 unary1, :369 guidance_unary, :393-394 linear + ReLU, :397-400 unary2, :414 residual + LeakyReLU), training
+ * mode (batch statistics).  A layer keeps its RAW output z = x W^T + b [R, C] and a record cst [6][C] of per-channel
+ * constants: sc = rstd * gamma, sh = beta - mean * sc (so y = act(z * sc + sh)), mean, rstd, and after its backward
+ * statistics D1, D0 (dz = g * sc + z * D1 + D0 with g = dy * act'(z * sc + sh)).  Consumers apply the normalisation while
+ * loading their operand tiles; statistics are finished by the last workgroup of the launch that produced the partial
+ * sums (no separate statistics / finalize / normalise launches).  `tickets`: a persistent, zero-initialised int buffer
+ * of pcf_hip_flin_ticket_ints() entries that the kernels leave zeroed; `workspace`: pcf_hip_flin_workspace_bytes().
+ * Activation codes: 0 none, 1 ReLU, 2 LeakyReLU(0.1), 3 sigmoid. */
+size_t pcf_hip_flin_workspace_bytes(long long rows, int c_out, int c_in);
+int pcf_hip_flin_ticket_ints(void);
+/* Z[M,N] = f(A)[M,K] W[N,K]^T + bias, f = act_pre(A * pre[0] + pre[1]) when `pre` (the producer's record) is given, else
+ * identity; `side` (nullable) receives f(A).  cst != null: batch statistics of Z -> cst rows 0..3 and the running
+ * statistics (momentum update with the unbiased variance, as nn.BatchNorm1d). */
+int pcf_hip_flin_forward(const float* A, long long M, int K, const float* pre, int pre_act, float* side, const float* W,
+                         const float* bias, int N, float* Z, float* cst, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, float eps, float momentum, void* workspace,
+                         size_t workspace_bytes, int* tickets, void* stream);
+/* dx[M,N] = dz[M,K] W[K,N] (+ add), dz from (dy, z, cst, act) of this layer.  With cstp != null the input was
+ * act_p(z_p * sc_p + sh_p): the BatchNorm-backward sums of that producing layer are taken from (dx, zp) and its dgamma,
+ * dbeta, zero bias gradient and record rows 4, 5 are written. */
+int pcf_hip_flin_backward_input(const float* dy, const float* z, const float* cst, int act, long long M, int K, const float* W,
+                                int N, const float* add, float* dx, const float* zp, float* cstp, int actp, float* dgamma_p,
+                                float* dbeta_p, float* dbias_p, void* workspace, size_t workspace_bytes, int* tickets, void* stream);
+/* dW[M,N] = sum_r dz[r,M]^T f(xin)[r,N], dz as above, f the producer's normalisation + activation (pre == null: identity):
+ * `_slabs` writes pcf_hip_flin_backward_weight_splits(R, M, N) partial products [splits][M][N] (one per row range);
+ * pcf_hip_slab_sum_multi adds the slab lists of up to 8 weight gradients in ONE launch, in a fixed order
+ * (out_i[e] = sum_s slabs_i[s][e], counts_i = M_i * N_i). */
+int pcf_hip_flin_backward_weight_splits(long long R, int M, int N);
+int pcf_hip_flin_backward_weight_slabs(const float* dy, const float* z, const float* cst, int act, const float* xin, const float* pre,
+                                       int pre_act, long long R, int M, int N, float* slabs, size_t slabs_bytes, void* stream);
+int pcf_hip_slab_sum_multi(int n, const float* const* slabs, float* const* out, const long long* counts, const int* splits,
+                           void* stream);
+/* Top of a chain, y = act(z * sc + sh + res): g = dy * act'(.) [R,C] (also the gradient of `res`), dgamma, dbeta, zero
+ * bias gradient and record rows 4, 5 of this layer. */
+int pcf_hip_bn_backward_stats(const float* dy, const float* z, const float* res, float* cst, int act, long long R, int C,
+                              float* g, float* dgamma, float* dbeta, float* dbias, void* workspace, size_t workspace_bytes, int* tickets,
+                              void* stream);
+
 /* ---- guided aggregate (PCF) ------------------------------------------------------------------
  * replaces pcf_cuda.pcf_forward / pcf_backward        (pcf_cuda.cpp:10-11, pcf.h:38-66,
  *                                                       pcf_ops.cu:27-71,87-141,143-202)

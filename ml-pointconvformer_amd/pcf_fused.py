@@ -860,3 +860,244 @@ def pcf_chain(vi, idx, u, fx, layers, training, fused_backward=True, g1_position
             W = g1_positional_weight if g1_positional_weight is not None else lin.weight[:, lin.weight.shape[1] - G:]
         params += [W, lin.bias, bn.weight, bn.bias]
     return _PCFChain.apply(idx, [bn for _, bn in layers], training, fused_backward, vi, u, fx, *params)
+
+
+# --------------------------------------------------------------------------------------------------
+# point-level Linear + BatchNorm chains of a PCFLayer (csrc/fused_linear.hip): the "head" in front of the edge graph
+# (unary1 -> guidance_unary -> per-point half of the first guidance layer) and the "tail" behind the aggregate
+# (linear + ReLU -> unary2 -> + shortcut -> LeakyReLU), training mode.  17 launches per step instead of ~45.
+# --------------------------------------------------------------------------------------------------
+_flin_ws = getattr(_lib, 'pcf_hip_flin_workspace_bytes')
+_flin_ws.argtypes = [_LL, _I, _I]
+_flin_ws.restype = _Z
+_flin_ticket_ints = getattr(_lib, 'pcf_hip_flin_ticket_ints')
+_flin_ticket_ints.argtypes = []
+_flin_ticket_ints.restype = _I
+_flin_fwd = _sig('pcf_hip_flin_forward', [_P, _LL, _I, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _F, _F, _P, _Z, _P, _P])
+_flin_bwd_in = _sig('pcf_hip_flin_backward_input', [_P, _P, _P, _I, _LL, _I, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _Z, _P, _P])
+_flin_bwd_w = _sig('pcf_hip_flin_backward_weight_slabs', [_P, _P, _P, _I, _P, _P, _I, _LL, _I, _I, _P, _Z, _P])
+_flin_bwd_w_splits = _sig('pcf_hip_flin_backward_weight_splits', [_LL, _I, _I])
+_slab_sum_multi = _sig('pcf_hip_slab_sum_multi', [_I, _PP, _PP, ctypes.POINTER(_LL), ctypes.POINTER(_I), _P])
+_bn_bwd_stats = _sig('pcf_hip_bn_backward_stats', [_P, _P, _P, _P, _I, _LL, _I, _P, _P, _P, _P, _P, _Z, _P, _P])
+
+_TICKETS = {}
+_IDENTITY_CST = {}
+
+
+def _tickets(dev):
+    """The persistent, zero-initialised ticket buffer of `dev` (the kernels leave it zeroed)."""
+    t = _TICKETS.get(dev)
+    if t is None:
+        t = _TICKETS[dev] = torch.zeros(_flin_ticket_ints(), dtype=torch.int32, device=dev)
+    return t
+
+
+def _identity_cst(dev, C):
+    """Record of a layer without BatchNorm and activation: sc = 1, sh = 0, mean = 0, rstd = 1, D1 = D0 = 0."""
+    t = _IDENTITY_CST.get((dev, C))
+    if t is None:
+        t = torch.zeros(6, C, dtype=torch.float32, device=dev)
+        t[0] = 1.0
+        t[3] = 1.0
+        _IDENTITY_CST[(dev, C)] = t
+    return t
+
+
+def _ws(dev, rows, cout, cin):
+    nbytes = _flin_ws(rows, cout, cin)
+    return torch.empty(nbytes, dtype=torch.uint8, device=dev), nbytes
+
+
+def _flin_forward(x2d, pre, pre_act, side, W, b, bn, momentum, stream, dev):
+    """z, cst of one layer (batch statistics, running statistics updated)."""
+    R, K = x2d.shape
+    N = W.shape[0]
+    z = torch.empty(R, N, dtype=torch.float32, device=dev)
+    cst = torch.empty(6, N, dtype=torch.float32, device=dev) if bn is not None else None
+    ws, nbytes = _ws(dev, R, N, K)
+    _call(_flin_fwd, _ptr(x2d), R, K, _ptr(pre), int(pre_act), _ptr(side), _ptr(W), _ptr(b), N, _ptr(z), _ptr(cst),
+          _ptr(bn.weight) if bn is not None else None, _ptr(bn.bias) if bn is not None else None,
+          _ptr(bn.running_mean) if bn is not None else None, _ptr(bn.running_var) if bn is not None else None,
+          float(bn.eps) if bn is not None else 0.0, float(momentum), ws.data_ptr(), nbytes, _tickets(dev).data_ptr(), stream)
+    return z, cst
+
+
+def _flin_bwd_input(dy, z, cst, act, W, add, zp, cstp, actp, grads_p, stream, dev):
+    """dx = dz W (+ add); with a producer (zp, cstp, actp) its dgamma / dbeta / zero bias gradient go to grads_p."""
+    R, K = dy.shape
+    N = W.shape[1]
+    dx = torch.empty(R, N, dtype=torch.float32, device=dev)
+    ws, nbytes = _ws(dev, R, K, N)
+    dg, dbe, dbi = grads_p if grads_p is not None else (None, None, None)
+    _call(_flin_bwd_in, _ptr(dy), _ptr(z), _ptr(cst), int(act), R, K, _ptr(W), N, _ptr(add), _ptr(dx), _ptr(zp), _ptr(cstp),
+          int(actp), _ptr(dg), _ptr(dbe), _ptr(dbi), ws.data_ptr(), nbytes, _tickets(dev).data_ptr(), stream)
+    return dx
+
+
+class _WeightGrads:
+    """Weight gradients of a chain: each product leaves its row-range slabs, one launch sums them all at the end."""
+
+    def __init__(self, dev, stream):
+        self.dev, self.stream, self.items = dev, stream, []
+
+    def add(self, dy, z, cst, act, xin, pre, pre_act):
+        R, M = dy.shape
+        N = xin.shape[1]
+        splits = _flin_bwd_w_splits(R, M, N)
+        slabs = torch.empty(splits, M, N, dtype=torch.float32, device=self.dev)
+        dW = torch.empty(M, N, dtype=torch.float32, device=self.dev)
+        _call(_flin_bwd_w, _ptr(dy), _ptr(z), _ptr(cst), int(act), _ptr(xin), _ptr(pre), int(pre_act), R, M, N, slabs.data_ptr(),
+              slabs.numel() * 4, self.stream)
+        self.items.append((slabs, dW, M * N, splits))
+        return dW
+
+    def finish(self):
+        n = len(self.items)
+        _call(_slab_sum_multi, n, _ptr_array([t[0] for t in self.items]), _ptr_array([t[1] for t in self.items]),
+              (_LL * n)(*[t[2] for t in self.items]), (_I * n)(*[t[3] for t in self.items]), self.stream)
+        self.items = []
+
+
+class _PointHead(torch.autograd.Function):
+    """(fx, u) = head(x): fx = LeakyReLU(BN1(x W1^T + b1)) (or x when the block has no unary1), guidance_x = BN2(fx W2^T + b2),
+    u = guidance_x Wa^T.  Three launches forward, six backward; keeps z1, z2 (raw) and two small records."""
+
+    @staticmethod
+    def forward(ctx, bns, x, Wa, W2, b2, g2, be2, W1=None, b1=None, g1=None, be1=None):
+        dev = x.device
+        shape = x.shape
+        x2 = x.reshape(-1, shape[-1])
+        bn1, bn2 = bns
+        stream = _stream(dev)
+        with _guard(dev):
+            if W1 is not None:
+                z1, cst1 = _flin_forward(x2, None, 0, None, W1, b1, bn1, bn_momentum(bn1), stream, dev)
+                count_batch(bn1)
+                fx = torch.empty(x2.shape[0], W1.shape[0], dtype=torch.float32, device=dev)
+                z2, cst2 = _flin_forward(z1, cst1, ACT_LEAKY, fx, W2, b2, bn2, bn_momentum(bn2), stream, dev)
+            else:
+                z1 = cst1 = None
+                fx = x2
+                z2, cst2 = _flin_forward(x2, None, 0, None, W2, b2, bn2, bn_momentum(bn2), stream, dev)
+            count_batch(bn2)
+            u, _ = _flin_forward(z2, cst2, ACT_NONE, None, Wa, None, None, 0.0, stream, dev)
+        ctx.save_for_backward(x2, z1, cst1, z2, cst2, u, Wa, W2, W1)
+        ctx.shape = shape
+        return fx.view(*shape[:-1], fx.shape[-1]), u.view(*shape[:-1], u.shape[-1])
+
+    @staticmethod
+    def backward(ctx, dfx, du):
+        x2, z1, cst1, z2, cst2, u, Wa, W2, W1 = ctx.saved_tensors
+        dev = x2.device
+        stream = _stream(dev)
+        R = x2.shape[0]
+        du2 = du.reshape(R, -1).contiguous()
+        dfx2 = dfx.reshape(R, -1).contiguous() if dfx is not None else None
+        f32 = dict(dtype=torch.float32, device=dev)
+        ident = _identity_cst(dev, Wa.shape[0])
+        G = W2.shape[0]
+        dg2, dbe2, db2 = torch.empty(G, **f32), torch.empty(G, **f32), torch.empty(G, **f32)
+        with _guard(dev):
+            wg = _WeightGrads(dev, stream)
+            dWa = wg.add(du2, du2, ident, ACT_NONE, z2, cst2, ACT_NONE)
+            dgx = _flin_bwd_input(du2, du2, ident, ACT_NONE, Wa, None, z2, cst2, ACT_NONE, (dg2, dbe2, db2), stream, dev)
+            if W1 is not None:
+                mid = W1.shape[0]
+                dg1, dbe1, db1 = torch.empty(mid, **f32), torch.empty(mid, **f32), torch.empty(mid, **f32)
+                dW2 = wg.add(dgx, z2, cst2, ACT_NONE, z1, cst1, ACT_LEAKY)
+                dfx_t = _flin_bwd_input(dgx, z2, cst2, ACT_NONE, W2, dfx2, z1, cst1, ACT_LEAKY, (dg1, dbe1, db1), stream, dev)
+                dW1 = wg.add(dfx_t, z1, cst1, ACT_LEAKY, x2, None, 0)
+                dx = _flin_bwd_input(dfx_t, z1, cst1, ACT_LEAKY, W1, None, None, None, 0, None, stream, dev) \
+                    if ctx.needs_input_grad[1] else None
+                tail = (dW1, db1, dg1, dbe1)
+            else:
+                dW2 = wg.add(dgx, z2, cst2, ACT_NONE, x2, None, 0)
+                dx = _flin_bwd_input(dgx, z2, cst2, ACT_NONE, W2, dfx2, None, None, 0, None, stream, dev) \
+                    if ctx.needs_input_grad[1] else None
+                tail = ()
+            wg.finish()
+        if dx is not None:
+            dx = dx.view(ctx.shape)
+        return (None, dx, dWa, dW2, db2, dg2, dbe2, *tail)
+
+
+class _PointTail(torch.autograd.Function):
+    """out = LeakyReLU(BN4(ReLU(BN3(agg W3^T + b3)) W4^T + b4) + shortcut).  Three launches forward, five backward."""
+
+    @staticmethod
+    def forward(ctx, bns, agg, shortcut, W3, b3, g3, be3, W4, b4, g4, be4):
+        dev = agg.device
+        shape = agg.shape
+        a2 = agg.reshape(-1, shape[-1])
+        bn3, bn4 = bns
+        stream = _stream(dev)
+        sc2 = shortcut.reshape(a2.shape[0], -1)
+        with _guard(dev):
+            z3, cst3 = _flin_forward(a2, None, 0, None, W3, b3, bn3, bn_momentum(bn3), stream, dev)
+            count_batch(bn3)
+            z4, cst4 = _flin_forward(z3, cst3, ACT_RELU, None, W4, b4, bn4, bn_momentum(bn4), stream, dev)
+            count_batch(bn4)
+            out = torch.empty_like(z4)
+            R, C = z4.shape
+            _call(_bnact_fwd, _ptr(z4), _ptr(sc2), R, C, cst4[2].data_ptr(), cst4[3].data_ptr(), _ptr(g4), _ptr(be4),
+                  ACT_LEAKY, _ptr(out), stream)
+        ctx.save_for_backward(a2, sc2, z3, cst3, z4, cst4, W3, W4)
+        ctx.shape = shape
+        return out.view(*shape[:-1], out.shape[-1])
+
+    @staticmethod
+    def backward(ctx, dout):
+        a2, sc2, z3, cst3, z4, cst4, W3, W4 = ctx.saved_tensors
+        dev = a2.device
+        stream = _stream(dev)
+        R = a2.shape[0]
+        d2 = dout.reshape(R, -1).contiguous()
+        f32 = dict(dtype=torch.float32, device=dev)
+        C4, C3 = W4.shape[0], W3.shape[0]
+        dg4, dbe4, db4 = torch.empty(C4, **f32), torch.empty(C4, **f32), torch.empty(C4, **f32)
+        dg3, dbe3, db3 = torch.empty(C3, **f32), torch.empty(C3, **f32), torch.empty(C3, **f32)
+        g = torch.empty_like(z4)
+        with _guard(dev):
+            ws, nbytes = _ws(dev, R, C4, C4)
+            _call(_bn_bwd_stats, _ptr(d2), _ptr(z4), _ptr(sc2), _ptr(cst4), ACT_LEAKY, R, C4, _ptr(g), _ptr(dg4), _ptr(dbe4),
+                  _ptr(db4), ws.data_ptr(), nbytes, _tickets(dev).data_ptr(), stream)
+            wg = _WeightGrads(dev, stream)
+            dW4 = wg.add(g, z4, cst4, ACT_NONE, z3, cst3, ACT_RELU)
+            dy3 = _flin_bwd_input(g, z4, cst4, ACT_NONE, W4, None, z3, cst3, ACT_RELU, (dg3, dbe3, db3), stream, dev)
+            dW3 = wg.add(dy3, z3, cst3, ACT_RELU, a2, None, 0)
+            dagg = _flin_bwd_input(dy3, z3, cst3, ACT_RELU, W3, None, None, None, 0, None, stream, dev) \
+                if ctx.needs_input_grad[1] else None
+            wg.finish()
+        if dagg is not None:
+            dagg = dagg.view(ctx.shape)
+        dsc = g.view(*ctx.shape[:-1], C4) if ctx.needs_input_grad[2] else None
+        return (None, dagg, dsc, dW3, db3, dg3, dbe3, dW4, db4, dg4, dbe4)
+
+
+def point_chain_ok(*bns):
+    """The fused point-level chains apply in training mode to plain (rank-local) BatchNorms with the exponential
+    running-statistics update."""
+    return all(isinstance(b, torch.nn.modules.batchnorm._BatchNorm) and b.training and b.momentum is not None
+               and b.track_running_stats and b.weight is not None and not cross_rank_bn(b) for b in bns)
+
+
+def point_head(x, unary1, guidance_unary, Wa):
+    """(fx, u) for a PCFLayer: unary1 (UnaryBlock with BatchNorm, or None when the block has none), guidance_unary
+    (UnaryBlock, no activation), Wa = the gathered half of the first guidance layer's weight."""
+    _floats(x=x)
+    l2 = guidance_unary.mlp
+    args = [Wa.contiguous(), l2.c.weight, l2.c.bias, l2.bn.weight, l2.bn.bias]
+    bn1 = None
+    if unary1 is not None:
+        l1 = unary1.mlp
+        bn1 = l1.bn
+        args += [l1.c.weight, l1.c.bias, l1.bn.weight, l1.bn.bias]
+    return _PointHead.apply((bn1, l2.bn), x.contiguous(), *args)
+
+
+def point_tail(agg, shortcut, linear, unary2):
+    """LeakyReLU(unary2(ReLU(linear(agg))) + shortcut) for two Linear_BN modules (layers.py:393-414)."""
+    _floats(agg=agg, shortcut=shortcut)
+    l4 = unary2.mlp
+    return _PointTail.apply((linear.bn, l4.bn), agg.contiguous(), shortcut.contiguous(), linear.c.weight, linear.c.bias,
+                            linear.bn.weight, linear.bn.bias, l4.c.weight, l4.c.bias, l4.bn.weight, l4.bn.bias)

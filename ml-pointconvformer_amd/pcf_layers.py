@@ -430,23 +430,31 @@ class PCFLayer(pcf_fused.CounterScope):
         ctr_xyz = sparse_xyz if strided else dense_xyz
         ctr_norm = sparse_xyz_norm if strided else dense_xyz_norm
         nei_inds = nei_inds.contiguous()
-        feats_x = self.unary1(dense_feats)
         _, wn_in = _edge_geometry(self.cfg.USE_VI is True, dense_xyz, dense_xyz_norm, nei_inds, ctr_xyz, ctr_norm,
                                   vi_features, want_rel=False)
-        guidance_x = self.guidance_unary(feats_x)
         chain = self._chain_layers(wn_in, nei_inds) if not strided else None
+        fused_points = self.training and not getattr(self.cfg, 'NO_POINT_CHAIN', False)
         if chain is not None:
             # self neighbourhoods, BatchNorm everywhere: the whole edge graph in four fused passes forward, three backward
             g1 = self.guidance_weight.mlp[0].c
-            G = guidance_x.shape[-1]
+            G = self.guidance_unary.out_dim
             Wa, Wb = pcf_fused.split_columns(g1.weight, G)      # gathered half | positional half
-            if self._zero8.device != Wa.device:
-                self._zero8 = self._zero8.to(Wa.device)
-            u = pcf_fused.linear_bn_act(guidance_x, Wa, self._zero8[:g1.out_features], None, pcf_fused.ACT_NONE, self.training)
+            u1 = self.unary1 if isinstance(self.unary1, UnaryBlock) else None
+            if fused_points and pcf_fused.point_chain_ok(self.guidance_unary.mlp.bn, *([u1.mlp.bn] if u1 is not None else [])):
+                # unary1 -> guidance_unary -> u in three launches (BatchNorms folded into the contractions)
+                feats_x, u = pcf_fused.point_head(dense_feats, u1, self.guidance_unary, Wa)
+            else:
+                feats_x = self.unary1(dense_feats)
+                guidance_x = self.guidance_unary(feats_x)
+                if self._zero8.device != Wa.device:
+                    self._zero8 = self._zero8.to(Wa.device)
+                u = pcf_fused.linear_bn_act(guidance_x, Wa, self._zero8[:g1.out_features], None, pcf_fused.ACT_NONE, self.training)
             agg = pcf_fused.pcf_chain(wn_in.contiguous(), nei_inds, u, feats_x.contiguous(), chain, self.training,
                                       fused_backward=not getattr(self.cfg, 'EDGE_CHAIN_LAYERWISE_BACKWARD', False),
                                       g1_positional_weight=Wb)
         else:
+            feats_x = self.unary1(dense_feats)
+            guidance_x = self.guidance_unary(feats_x)
             feat_pe = _linear_act(self.mlp_conv, wn_in, pcf_fused.ACT_RELU)
             if isinstance(self.guidance_weight, MultiHeadGuidanceQK) or self.guidance_weight.layer_norm:
                 # ablations (layers.py:370-381): the query tensor is formed, the key is its centre row / maximum over K
@@ -468,6 +476,11 @@ class PCFLayer(pcf_fused.CounterScope):
                               inv_neighbors, inv_k, inv_idx)
         sparse_feats = pcf_fused.gather_max(dense_feats, nei_inds) if strided else dense_feats
         shortcut = self.unary_shortcut(sparse_feats)
+        if fused_points and isinstance(self.linear, Linear_BN) and isinstance(self.dropout, nn.Identity) \
+                and not (isinstance(self.drop_path, DropPath) and self.drop_path.drop_prob > 0.) \
+                and pcf_fused.point_chain_ok(self.linear.bn, self.unary2.mlp.bn):
+            # linear + ReLU -> unary2 -> + shortcut -> LeakyReLU in three launches forward, five backward
+            return pcf_fused.point_tail(agg, shortcut, self.linear, self.unary2), wn_in
         # leaky_relu(drop_path(unary2(.)) + shortcut)   (layers.py:397-414; drop_path_rate 0.2 in configPCF_2cm_PTF2)
         new_feat = _residual_tail(self.unary2, self.drop_path, self.dropout(_linear_act(self.linear, agg, pcf_fused.ACT_RELU)),
                                   shortcut, pcf_fused.ACT_LEAKY)
