@@ -38,6 +38,9 @@ import torch.distributed as dist
 
 N_POINTS, K_NEI, C_FEAT, HEADS, C_MID, GUID = 80000, 16, 64, 8, 16, 32
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_*_f32)
+# SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES of the entry point's kernels, time-weighted (profiles/r02_pmc_sq_counters.txt)
+MFMA_BUSY = {'pcf_hip_pcf_chain_forward': 0.35, 'pcf_hip_pcf_chain_backward': 0.36}
 
 # Algorithmic HBM bytes per point of the aggregate operator, fp32 + int64 indices.
 def _agg_bytes(Ci, Cm, H, K):
@@ -67,14 +70,28 @@ def synth_cloud(n, seed):
     return xyz, nrm, feats
 
 
-def cpu_baseline(state_dict, xyz, nrm, feats, idx, iters=3):
-    """The oracle's restatement of PCFLayer fwd+bwd on the host cores (kind = "port")."""
-    from oracle import pcf_oracle as O
+def _host_cores():
     try:
-        cores = len(os.sched_getaffinity(0))
+        return len(os.sched_getaffinity(0))
     except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 16))        # a 1-GPU box's CPU share; more threads than that only thrash
+        return os.cpu_count() or 1
+
+
+def _cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown CPU'
+
+
+def cpu_baseline(state_dict, xyz, nrm, feats, idx, iters=5):
+    """the oracle's restatement of PCFLayer fwd+bwd on ALL host cores this process may use
+    (kind = "port"), 1 warm-up + `iters` >= 5 timed iterations, median."""
+    from oracle import pcf_oracle as O
+    cores = _host_cores()
     torch.set_num_threads(cores)
     sd = {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point() and 'running' not in k)
           for k, v in state_dict.items()}
@@ -98,8 +115,49 @@ def cpu_baseline(state_dict, xyz, nrm, feats, idx, iters=3):
     ts.sort()
     med = ts[len(ts) // 2]
     return {'value': round(xyz.shape[1] / med, 1), 'unit': 'points/s', 'cores': torch.get_num_threads(),
-            'kind': 'port', 'sample': f'full workload N={xyz.shape[1]} K={idx.shape[2]}, 1 warm-up + {iters} timed '
-            f'iterations, median {med * 1e3:.0f} ms; oracle/pcf_oracle.py:pcf_layer on torch CPU'}
+            'kind': 'port', 'cpu': _cpu_model(),
+            'sample': f'full workload N={xyz.shape[1]} K={idx.shape[2]}, 1 warm-up + {iters} timed iterations, median '
+            f'{med * 1e3:.0f} ms; oracle/pcf_oracle.py:pcf_layer on torch CPU, all {cores} cores of the process affinity mask'}
+
+
+def cpu_baseline_pointconv(iters=5, n=4096, k=16):
+    """BASELINE.md section 3b / BASELINE.json configs[0]: single PointConv(3 -> 32, weightnet [3, 16]), USE_VI = USE_PE =
+    BATCH_NORM = False, N = 4096, K = 16, fwd + backward on the host cores (the reference's CPU-runnable case)."""
+    from oracle import pcf_oracle as O
+    g = torch.Generator().manual_seed(1)
+    xyz = torch.rand(1, n, 3, generator=g)
+    feats = torch.randn(1, n, 3, generator=g).requires_grad_(True)
+    idx = torch.from_numpy(O.knn_bruteforce(xyz[0].numpy(), xyz[0].numpy(), k))[None]
+    sd = {}
+    for i, (a, b) in enumerate(((3, 8), (8, 8), (8, 16))):          # WeightNet 3 -> 8 -> 8 -> 16 (layers.py:127-171)
+        sd[f'weightnet.mlp_convs.{i}.c.weight'] = torch.randn(b, a, generator=g) / a ** 0.5
+        sd[f'weightnet.mlp_convs.{i}.c.bias'] = torch.zeros(b)
+        sd[f'weightnet.mlp_convs.{i}.bn.weight'] = torch.ones(b)
+        sd[f'weightnet.mlp_convs.{i}.bn.bias'] = torch.zeros(b)
+    sd['linear.weight'] = torch.randn(32, 48, generator=g) / 48 ** 0.5
+    sd['linear.bias'] = torch.zeros(32)
+    for v in sd.values():
+        v.requires_grad_(True)
+    P = O.Params(sd, '', True)
+
+    def step():
+        out, _ = O.pointconv_layer(P, xyz, feats, idx, use_vi=False, use_pe=False)
+        out.sum().backward()
+        for v in sd.values():
+            v.grad = None
+        feats.grad = None
+
+    step()
+    ts = []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        step()
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    med = ts[len(ts) // 2]
+    return {'value': round(n / med, 1), 'unit': 'points/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'test_configs/pointconv_single.yaml layer: PointConv(3->32, weightnet [3,16]) fwd+bwd, N={n} K={k}, '
+                      f'1 warm-up + {iters} timed iterations, median {med * 1e3:.1f} ms'}
 
 
 LITE_GRID = [0.1, 0.2, 0.4, 0.8, 1.6]        # configs/configPCF_10cm_lite.yaml grid_size (subsample workload)
@@ -321,7 +379,7 @@ def main():
     params = list(layer.parameters())        # walking the module tree every step costs ~0.1 ms of host time
     # N > 1: one flat bucket of the 13.7 k gradient floats, packed inside the replayed graph, one RCCL all-reduce and
     # one multi-tensor copy back per step (DDP's per-step hooks need eager launches: ~20 % slower steps)
-    bucket = pcf_dist.GradBucket(params) if (world > 1 and not args.no_graph) else None
+    bucket = pcf_dist.GradBucket(params, list(layer.buffers())) if (world > 1 and not args.no_graph) else None
     if bucket is not None:
         bucket.broadcast_parameters()
     elif world > 1:
@@ -434,28 +492,62 @@ def main():
     hip_ms_all = {k: sum(v) / len(v) for k, v in per_all.items()}
     hip_total_ms = sum(sum(v) for v in per_all.values()) / 3
 
+    # eager steps (what a training loop without graph capture sees), timed the same way
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eager_step()
+    fence()
+    eager_ms = pcf_dist.max_over_ranks(time.perf_counter() - t0, dev) / args.steps * 1e3
+
     if rank == 0:
         Ci = C_FEAT // 4
         fwd_b, bwd_b = _agg_bytes(Ci, C_MID, HEADS, K_NEI)
-        cand = {'pcf_hip_pcf_forward': (fwd_b, 'agg_fwd_fx_mfma_kernel'),
-                'pcf_hip_pcf_backward': (bwd_b, 'agg_bwd_fx_mfma_kernel'),
-                'pcf_hip_pcf_backward_csr': (bwd_b, 'agg_bwd_kernel<16,true,false,true> + csr_reduce_kernel')}
-        dom = max((k for k in cand if k in hip_ms), key=lambda k: hip_ms[k])
-        bytes_per_launch = cand[dom][0] * n
-        achieved = bytes_per_launch / (hip_ms[dom] * 1e-3) / 1e9
-        traffic = None     # HBM bytes per launch from the PMC counters (profiles/r01h_pmc_traffic.json), same shape only
-        try:
+        ms_per_step = elapsed / args.steps * 1e3
+        # Algorithmic work per point of the entry points that can dominate the step: bytes for the
+        # HBM-bound aggregate, flops of the per-edge MLPs (mlp_conv 12 288 + guidance MLP 18 432 + WeightNet 9 216
+        # = 39 936 forward, 2x backward) for the MFMA-bound edge graph.
+        EDGE_FLOP_FWD = 12288 + 18432 + 9216
+        cand = {
+            'pcf_hip_pcf_forward': ('hbm', fwd_b, 'agg_fwd_fx_mfma_kernel'),
+            'pcf_hip_pcf_backward': ('hbm', bwd_b, 'agg_bwd_fx_mfma_kernel (+ grad_x memset)'),
+            'pcf_hip_pcf_backward_csr': ('hbm', bwd_b, 'agg_bwd_kernel<16,true,fx> + csr_reduce_kernel'),
+            'pcf_hip_pcf_chain_forward': ('mfma', EDGE_FLOP_FWD, 'pcf_chain_kernel<1,2> + pcf_chain_tail_kernel<stats|final> + 3 finalize'),
+            'pcf_hip_pcf_chain_backward': ('mfma', 2 * EDGE_FLOP_FWD, 'pcf_chain_bwd_kernel<1,2,3> + 2 finalize + reduce + combine'),
+        }
+
+        def block(name, ms):
+            bound, per_point, kernels = cand[name]
+            work = per_point * n
+            if bound == 'hbm':
+                ach = work / (ms * 1e-3) / 1e9
+                b = {'bound': 'hbm', 'kernel': kernels, 'entry_point': name, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS,
+                     'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': None, 'algorithmic_bytes_per_launch': work}
+            else:
+                ach = work / (ms * 1e-3) / 1e12
+                b = {'bound': 'mfma', 'kernel': kernels, 'entry_point': name, 'achieved': round(ach, 2), 'peak': MFMA_F32_PEAK_TF,
+                     'unit': 'TFLOP/s', 'frac': round(ach / MFMA_F32_PEAK_TF, 4), 'traffic': None, 'algorithmic_flop_per_launch': work,
+                     'mfma_busy_frac': MFMA_BUSY.get(name)}
+            b['avg_launch_ms'] = round(ms, 4)
+            return b
+
+        # dominant = the bracketed entry point with the largest device time per step, over ALL entry points of the step
+        per_step = {k: sum(v) / 3 for k, v in per_all.items()}
+        dom = max(per_step, key=per_step.get)
+        roofline = block(dom, hip_ms_all[dom]) if dom in cand else {
+            'bound': 'hbm', 'kernel': dom, 'entry_point': dom, 'achieved': None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': None,
+            'traffic': None, 'avg_launch_ms': round(hip_ms_all[dom], 4)}
+        gather = max((k for k in ('pcf_hip_pcf_forward', 'pcf_hip_pcf_backward', 'pcf_hip_pcf_backward_csr') if k in hip_ms),
+                     key=lambda k: hip_ms[k])
+        roofline_gather = block(gather, hip_ms[gather])
+        try:       # HBM bytes per launch from the PMC counters (profiles/r01h_pmc_traffic.json), same shape only
             pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01h_pmc_traffic.json')))
             if pmc['shape'] == {'N': n, 'K': K_NEI, 'Ci': Ci, 'Cm': C_MID, 'H': HEADS}:
-                traffic = pmc['kernels'].get(cand[dom][1], {}).get('traffic_bytes')
+                roofline_gather['traffic'] = pmc['kernels'].get(cand[gather][2].split(' ')[0], {}).get('traffic_bytes')
         except (OSError, ValueError, KeyError):
             pass
-        roofline = {'bound': 'hbm', 'kernel': cand[dom][1], 'entry_point': dom,
-                    'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
-                    'algorithmic_bytes_per_launch': bytes_per_launch,
-                    'avg_launch_ms': round(hip_ms[dom], 4)}
-        ms_per_step = elapsed / args.steps * 1e3
+        step_flop = 3 * 73696 * n                 # 73 696 flop/point forward, fwd+bwd counted as 3x
+        step_bytes = 3 * 4312 * n                 # fused-ideal compulsory bytes, 4312 B/point forward, same 3x
         line = {
             'metric': 'PCFLayer fwd+bwd points/sec (N=80k,K=16,C=64)',
             'value': round(pcf_dist.whole_job_rate(n, args.steps, world, elapsed), 1), 'unit': 'points/s',
@@ -465,13 +557,24 @@ def main():
                                    f'N={n} K={K_NEI} per GPU (BASELINE configs[1]-class layer; metric shape)',
                        'points_per_gpu': n, 'K': K_NEI, 'C': C_FEAT, 'parallelism': f'dp{world}'},
             'roofline': roofline,
+            'roofline_gather': roofline_gather,
+            'whole_step': {'flop': step_flop, 'bytes_ideal': step_bytes,
+                           'frac_mfma': round(step_flop / (ms_per_step * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4),
+                           'frac_hbm': round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
             'hip_ms_per_call': {k: round(v, 4) for k, v in sorted(hip_ms_all.items())},
+            'hip_ms_per_entry_point_per_step': {k: round(v, 4) for k, v in sorted(per_step.items())},
             'hip_ms_per_step': round(hip_total_ms, 4),
+            'eager_ms_per_step': round(eager_ms, 4),
             'knn_ms': round(knn_ms, 3), 'csr_ms': round(csr_ms, 3), 'hip_graph': graph is not None,
+            'step_path': ('HIP-graph replay' if graph is not None else 'eager launches') +
+                         ('' if world == 1 else (' + one flat-bucket RCCL all-reduce per step' if bucket is not None
+                                                 else ' under DistributedDataParallel')),
+            'collective_backend': None if world == 1 else dist.get_backend(), 'world_size': world,
             'grad_sync': None if world == 1 else ('one flat-bucket all-reduce per step' if bucket is not None else 'DistributedDataParallel'),
         }
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(layer.state_dict(), xyz, nrm, feats.detach(), idx)
+            line['cpu_baseline_pointconv_single'] = cpu_baseline_pointconv()
         print(json.dumps(line), flush=True)
     pcf_dist.shutdown()
 

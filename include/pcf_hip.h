@@ -241,6 +241,18 @@ int pcf_hip_grid_subsample(const float* points, const float* features, const int
                            int F, float sampleDl, float* out_points, float* out_features, int32_t* out_seg_counts,
                            int32_t* out_total, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- level-0 voxelisation: at most one point per occupied voxel --------------------------------------------------
+ * replaces util/voxelize.py:44-82 `voxelize(coord, voxel_size, hash_type='fnv', mode=...)`, which thins the raw scan to the
+ * level-0 resolution in the dataloader (scannet_data_loader_color_DDP.py:210-215).  points [N,3] f32 (one cloud);
+ * key = FNV64-1A of floor(coord / voxel_size) per axis as uint64 (the quotient in double, as numpy computes it);
+ * out_index i64 [N] (room for N) receives the chosen point of every voxel in ascending key order -- the reference's
+ * idx_sort order --; mode 0: the voxel's first point in index order ('deterministic'), 1: a pseudo-random point
+ * (splitmix64 of seed and voxel rank: 'random'), 2: point `rank` mod the voxel's count (one set of 'multiple').
+ * out_total i32 [2] = {voxels, points in the fullest voxel}. */
+size_t pcf_hip_voxelize_workspace_bytes(int n_points);
+int pcf_hip_voxelize(const float* points, int n_points, double voxel_size, int mode, unsigned long long seed, int rank,
+                     int64_t* out_index, int32_t* out_total, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- per-edge helpers around the aggregate ---------------------------------------------------
  * replace index_points (layer_utils.py:13-30) and its index_put_ backward: */
 /* out[b,s,:] = table[b, idx[b,s], :]   table [B,N,C], idx [B,S] i64 (S = M*K for a neighbour table) */

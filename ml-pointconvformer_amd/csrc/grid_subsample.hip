@@ -164,6 +164,55 @@ __global__ __launch_bounds__(BLOCK) void voxel_mean_kernel(const float* __restri
     }
 }
 
+// ---- level-0 voxelisation: one point per occupied voxel (util/voxelize.py:44-82) ----------------------------------
+// key = FNV64-1A over floor(coord / voxel_size) taken as uint64 per axis (:10-22, :58-62).  The division runs in double:
+// numpy promotes the float32 coordinates against the 0-d float64 array np.array(voxel_size) (:58).
+__global__ __launch_bounds__(BLOCK) void fnv_key_kernel(const float* __restrict__ pts, int n, double voxel,
+                                                        unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals) {
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        unsigned long long h = 14695981039346656037ull;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double d = floor((double)pts[3 * (size_t)i + a] / voxel);
+            h *= 1099511628211ull;
+            h ^= (unsigned long long)(long long)d;          // astype(uint64) of a (possibly negative) whole number
+        }
+        keys[i] = h;
+        vals[i] = (uint32_t)i;
+    }
+}
+// run starts of the sorted keys: start[v] = first sorted position of voxel v, start[total] = n; total, longest run
+__global__ __launch_bounds__(BLOCK) void vox_start_kernel(const unsigned long long* __restrict__ keys, const int32_t* __restrict__ vid,
+                                                          int n, int32_t* __restrict__ start, int32_t* __restrict__ total) {
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        if (i == 0 || keys[i] != keys[i - 1]) start[vid[i]] = i;
+        if (i == n - 1) { start[vid[n]] = n; total[0] = vid[n]; }
+    }
+}
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+// mode 0: first point of the voxel (lowest index: the sort is stable); 1: a pseudo-random one (seed); 2: point `rank % count`
+__global__ __launch_bounds__(BLOCK) void vox_pick_kernel(const uint32_t* __restrict__ order, const int32_t* __restrict__ start,
+                                                         int32_t* __restrict__ total, int n, int mode, unsigned long long seed,
+                                                         int rank, int64_t* __restrict__ out) {
+    const int nv = total[0];
+    int longest = 0;
+    for (int v = blockIdx.x * BLOCK + threadIdx.x; v < nv && v < n; v += gridDim.x * BLOCK) {
+        const int beg = start[v], cnt = start[v + 1] - beg;
+        int off = 0;
+        if (mode == 1) off = (int)(splitmix64(seed ^ (unsigned long long)v * 0x9E3779B97F4A7C15ull) % (unsigned long long)cnt);
+        else if (mode == 2) off = rank % cnt;
+        out[v] = (int64_t)order[beg + off];
+        longest = max(longest, cnt);
+    }
+    for (int off = WAVE / 2; off > 0; off >>= 1) longest = max(longest, __shfl_xor(longest, off, WAVE));
+    if (lane_id() == 0 && longest > 0) atomicMax(&total[1], longest);
+}
+
 struct SubWs {
     size_t off_boxes, off_keys_a, off_keys_b, off_vals_a, off_vals_b, off_flags, off_vid, off_chunks, off_start, off_sort, sort_bytes,
         bytes;
@@ -247,6 +296,47 @@ int pcf_hip_grid_subsample(const float* points, const float* features, const int
                        out_points, out_features);
 #undef PCF_HIP
     return check_launch("grid_subsample: means");
+}
+
+size_t pcf_hip_voxelize_workspace_bytes(int n_points) {
+    if (n_points < 0) return 0;
+    return pcf::sub_plan(n_points, 1).bytes;
+}
+
+int pcf_hip_voxelize(const float* points, int n_points, double voxel_size, int mode, unsigned long long seed, int rank,
+                     int64_t* out_index, int32_t* out_total, void* workspace, size_t workspace_bytes, void* stream) {
+    using namespace pcf;
+    PCF_REQUIRE(n_points >= 0 && voxel_size > 0.0 && mode >= 0 && mode <= 2 && rank >= 0, "voxelize: bad arguments (n=%d voxel=%g mode=%d)",
+                n_points, voxel_size, mode);
+    PCF_REQUIRE(out_total, "voxelize: null count output");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(out_total, 0, 2 * sizeof(int32_t), s) != hipSuccess) return fail(PCF_E_LAUNCH, "voxelize: memset");
+    if (n_points == 0) return ok();
+    const SubWs w = sub_plan(n_points, 1);
+    PCF_REQUIRE(points && out_index && workspace && aligned16(workspace) && workspace_bytes >= w.bytes,
+                "voxelize: null pointer or small / misaligned workspace");
+    char* ws = static_cast<char*>(workspace);
+    auto* keys_a = reinterpret_cast<unsigned long long*>(ws + w.off_keys_a);
+    auto* keys_b = reinterpret_cast<unsigned long long*>(ws + w.off_keys_b);
+    auto* vals_a = reinterpret_cast<uint32_t*>(ws + w.off_vals_a);
+    auto* vals_b = reinterpret_cast<uint32_t*>(ws + w.off_vals_b);
+    int32_t* flags = reinterpret_cast<int32_t*>(ws + w.off_flags);
+    int32_t* vid = reinterpret_cast<int32_t*>(ws + w.off_vid);
+    int32_t* chunks = reinterpret_cast<int32_t*>(ws + w.off_chunks);
+    int32_t* start = reinterpret_cast<int32_t*>(ws + w.off_start);
+    const int n = n_points;
+    const int pgrid = std::max(1, std::min(ceil_div(n, BLOCK), 4096));
+    hipLaunchKernelGGL(fnv_key_kernel, dim3(pgrid), dim3(BLOCK), 0, s, points, n, voxel_size, keys_a, vals_a);
+    if (int e = check_launch("voxelize: keys")) return e;
+    size_t sb = w.sort_bytes;
+    if (rocprim::radix_sort_pairs(ws + w.off_sort, sb, (const unsigned long long*)keys_a, keys_b, (const uint32_t*)vals_a, vals_b,
+                                  (size_t)n, 0, 64, s) != hipSuccess)
+        return fail(PCF_E_LAUNCH, "voxelize: radix sort");
+    hipLaunchKernelGGL(run_head_kernel, dim3(pgrid), dim3(BLOCK), 0, s, keys_b, n, flags);
+    if (int e = exclusive_scan_i32(flags, chunks, vid, n, false, s)) return e;
+    hipLaunchKernelGGL(vox_start_kernel, dim3(pgrid), dim3(BLOCK), 0, s, keys_b, vid, n, start, out_total);
+    hipLaunchKernelGGL(vox_pick_kernel, dim3(pgrid), dim3(BLOCK), 0, s, vals_b, start, out_total, n, mode, seed, rank, out_index);
+    return check_launch("voxelize: pick");
 }
 
 }  // extern "C"

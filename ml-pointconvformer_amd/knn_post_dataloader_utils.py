@@ -241,3 +241,23 @@ def subsample_packed(coord, norm, points_stored0, grid_size, min_points=16):
         norms.append(sf.contiguous())
         stored.append(list(sc))
     return [t[None] for t in pointclouds], [t[None] for t in norms], stored
+
+
+def voxelize(coord, voxel_size=0.05, hash_type='fnv', mode='random', seed=None):
+    """``util.voxelize.voxelize`` (util/voxelize.py:44-82) on the GPU: indices of at most one point per occupied voxel, in
+    ascending hash-key order like the reference's ``idx_sort``.  coord: [N,3] numpy array or tensor.  'deterministic'
+    returns the lowest point index of every voxel (the reference returns whichever point its unstable argsort put first);
+    'random' one pseudo-random point per voxel (torch's global seed unless `seed` is given); 'multiple' the list of
+    index sets that together cover every point.  Only the FNV hash (the reference's default, the one its data loader
+    uses: scannet_data_loader_color_DDP.py:210) is built."""
+    if hash_type != 'fnv':
+        raise NotImplementedError("voxelize: only hash_type='fnv' is built (util/voxelize.py:58-62)")
+    pts = _as_device_points(coord)
+    if mode == 'deterministic':
+        return pcf_cuda.voxelize(pts, voxel_size, 'deterministic')[0]
+    if mode == 'multiple':
+        first, longest = pcf_cuda.voxelize(pts, voxel_size, 'rank', rank=0)
+        return [first] + [pcf_cuda.voxelize(pts, voxel_size, 'rank', rank=i)[0] for i in range(1, longest)]
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    return pcf_cuda.voxelize(pts, voxel_size, 'random', seed=seed)[0]

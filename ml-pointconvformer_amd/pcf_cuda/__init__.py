@@ -32,7 +32,7 @@ import torch
 __all__ = [
     'pcf_forward', 'pcf_backward', 'pconv_forward', 'pconv_backward', 'pconv_linear_forward',
     'pconv_linear_backward', 'pconv_linear_opt_backward', 'compute_knn_inverse',
-    'pconv_linear_cutlass_forward', 'pcf_backward_csr', 'knn_packed', 'gemm_nt', 'library_path', 'version',
+    'pconv_linear_cutlass_forward', 'pcf_backward_csr', 'knn_packed', 'gemm_nt', 'voxelize', 'grid_subsample', 'library_path', 'version',
 ]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -78,6 +78,8 @@ _inv_batch_ws = _sig('pcf_hip_knn_inverse_batched_workspace_bytes', [_I, _IP, _I
 _inv_batch = _sig('pcf_hip_knn_inverse_batched', [_I, _PP, _PP, _PP, _PP, _IP, _IP, _IP, _P, _Z, _P])
 _gridsub_ws = _sig('pcf_hip_grid_subsample_workspace_bytes', [_I, _I], _Z)
 _gridsub = _sig('pcf_hip_grid_subsample', [_P, _P, _P, _I, _I, _I, ctypes.c_float, _P, _P, _P, _P, _P, _Z, _P])
+_vox_ws = _sig('pcf_hip_voxelize_workspace_bytes', [_I], _Z)
+_vox = _sig('pcf_hip_voxelize', [_P, _I, ctypes.c_double, _I, ctypes.c_ulonglong, _I, _P, _P, _P, _Z, _P])
 _knn_grid = _sig('pcf_hip_knn_grid', [_P] * 4 + [_I] * 4 + [_P, _P, _Z, _P])
 _knn_wave = _sig('pcf_hip_knn_wave', [_P] * 4 + [_I] * 3 + [_P] * 2)
 _gemm_nt = _sig('pcf_hip_gemm_nt', [_P] * 4 + [_I] * 3 + [_P])
@@ -526,6 +528,30 @@ def knn_packed(ref, query, ref_offsets, query_offsets, K, method='auto'):
             _call(_knn, _ptr(ref), _ptr(query), ref_offsets.data_ptr(), query_offsets.data_ptr(), S, n_query, int(K),
                   _ptr(out), _stream(dev))
     return out
+
+
+_VOX_MODES = {'deterministic': 0, 'random': 1, 'rank': 2}
+
+
+def voxelize(points, voxel_size, mode='deterministic', seed=0, rank=0):
+    """At most one point per occupied voxel (util/voxelize.py:44-82 on the GPU, FNV hash).  points [N,3] f32 device
+    tensor of ONE cloud -> (idx int64 [V] in ascending key order, fullest-voxel count).  mode 'deterministic': the voxel's
+    lowest point index; 'random': a pseudo-random point of the voxel from `seed`; 'rank': point `rank` mod count.  Reading
+    V back is the one device->host sync (data-dependent output size)."""
+    _floats(points=points)
+    if points.dim() != 2 or points.shape[1] != 3:
+        raise RuntimeError('pcf_cuda: points must be [n,3]')
+    n = points.shape[0]
+    dev = points.device
+    out = torch.empty(n, dtype=torch.int64, device=dev)
+    meta = torch.empty(2, dtype=torch.int32, device=dev)
+    with _guard(dev):
+        nbytes = _vox_ws(n)
+        ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=dev)
+        _call(_vox, _ptr(points), n, float(voxel_size), _VOX_MODES[mode], int(seed) & (2 ** 64 - 1), int(rank), out.data_ptr(),
+              meta.data_ptr(), ws.data_ptr(), nbytes, _stream(dev))
+    total, longest = meta.cpu().tolist()
+    return out[:total], longest
 
 
 def grid_subsample(points, features=None, offsets=None, sampleDl=0.1):

@@ -56,16 +56,9 @@ def baseline_config(name):
 
 def _voxelize_first(xyz, grid):
     """One point per occupied voxel of edge `grid` (the first in index order) -> indices, ascending: the deterministic
-    mode of util/voxelize.py:44-82, which thins the raw scan to the level-0 resolution."""
-    v = torch.floor(xyz / grid).to(torch.int64)
-    v = v - v.min(0, keepdim=True)[0]
-    dims = v.max(0)[0] + 1
-    key = (v[:, 0] * dims[1] + v[:, 1]) * dims[2] + v[:, 2]
-    order = torch.argsort(key, stable=True)
-    ks = key[order]
-    first = torch.ones_like(ks, dtype=torch.bool)
-    first[1:] = ks[1:] != ks[:-1]
-    return torch.sort(order[first])[0]
+    mode of util/voxelize.py:44-82, which thins the raw scan to the level-0 resolution -- on the GPU
+    (knn_post_dataloader_utils.voxelize -> pcf_hip_voxelize)."""
+    return torch.sort(knn_utils.voxelize(xyz, grid, mode='deterministic'))[0]
 
 
 def synthetic_scene(n_points, grid_sizes, seed, device, n_features=3, n_classes=20):
