@@ -103,6 +103,26 @@ int pcf_hip_bn_backward_stats(const float* dy, const float* z, const float* res,
                               float* g, float* dgamma, float* dbeta, float* dbias, void* workspace, size_t workspace_bytes, int* tickets,
                               void* stream);
 
+/* ---- attention arithmetic of the ablation layers ------------------------------------------------
+ * softmax_aggregate: PointTransformerLayer.forward, layers.py:519-527.  v [R,K,C], logit [R,K,J] (J divides C: the
+ *   share_planes groups) -> sm = softmax over K of logit (saved for the backward), out[r,c] = sum_k v[r,k,c] * sm[r,k,c % J].
+ * qk_score: MultiHeadGuidanceQK.forward, layers.py:100-114.  q [R,K,H,D], key [R,H,D] -> sigmoid(scale * <q, key>) [R,K,H].
+ * layer_norm: nn.LayerNorm over the last axis (layers.py:33-36, 52-53), x [R,C]; mean / rstd [R] are saved for the backward. */
+int pcf_hip_softmax_aggregate_forward(const float* v, const float* logit, float* out, float* sm, long long R, int K, int C,
+                                      int J, void* stream);
+int pcf_hip_softmax_aggregate_backward(const float* dout, const float* v, const float* sm, float* dv, float* dlogit,
+                                       long long R, int K, int C, int J, void* stream);
+int pcf_hip_qk_score_forward(const float* q, const float* key, float* score, long long R, int K, int H, int D, float scale,
+                             void* stream);
+int pcf_hip_qk_score_backward(const float* dscore, const float* score, const float* q, const float* key, float* dq, float* dkey,
+                              long long R, int K, int H, int D, float scale, void* stream);
+int pcf_hip_layer_norm_forward(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                               long long R, int C, float eps, void* stream);
+size_t pcf_hip_layer_norm_backward_workspace_bytes(long long R, int C);
+int pcf_hip_layer_norm_backward(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                                float* dx, float* dgamma, float* dbeta, long long R, int C, void* workspace,
+                                size_t workspace_bytes, void* stream);
+
 /* ---- guided aggregate (PCF) ------------------------------------------------------------------
  * replaces pcf_cuda.pcf_forward / pcf_backward        (pcf_cuda.cpp:10-11, pcf.h:38-66,
  *                                                       pcf_ops.cu:27-71,87-141,143-202)

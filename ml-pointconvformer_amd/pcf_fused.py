@@ -1101,3 +1101,121 @@ def point_tail(agg, shortcut, linear, unary2):
     l4 = unary2.mlp
     return _PointTail.apply((linear.bn, l4.bn), agg.contiguous(), shortcut.contiguous(), linear.c.weight, linear.c.bias,
                             linear.bn.weight, linear.bn.bias, l4.c.weight, l4.c.bias, l4.bn.weight, l4.bn.bias)
+
+
+# --------------------------------------------------------------------------------------------------
+# attention arithmetic of the ablation layers (csrc/attention_ops.hip)
+# --------------------------------------------------------------------------------------------------
+_sm_agg_fwd = _sig('pcf_hip_softmax_aggregate_forward', [_P, _P, _P, _P, _LL, _I, _I, _I, _P])
+_sm_agg_bwd = _sig('pcf_hip_softmax_aggregate_backward', [_P, _P, _P, _P, _P, _LL, _I, _I, _I, _P])
+_qk_fwd = _sig('pcf_hip_qk_score_forward', [_P, _P, _P, _LL, _I, _I, _I, _F, _P])
+_qk_bwd = _sig('pcf_hip_qk_score_backward', [_P, _P, _P, _P, _P, _P, _LL, _I, _I, _I, _F, _P])
+_ln_fwd = _sig('pcf_hip_layer_norm_forward', [_P, _P, _P, _P, _P, _P, _LL, _I, _F, _P])
+_ln_bwd_ws = getattr(_lib, 'pcf_hip_layer_norm_backward_workspace_bytes')
+_ln_bwd_ws.argtypes = [_LL, _I]
+_ln_bwd_ws.restype = _Z
+_ln_bwd = _sig('pcf_hip_layer_norm_backward', [_P, _P, _P, _P, _P, _P, _P, _P, _LL, _I, _P, _Z, _P])
+
+
+class _SoftmaxAggregate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, v, logit):
+        v, logit = v.contiguous(), logit.contiguous()
+        B, M, K, C = v.shape
+        J = logit.shape[-1]
+        dev = v.device
+        out = torch.empty(B, M, C, dtype=torch.float32, device=dev)
+        sm = torch.empty_like(logit)
+        with _guard(dev):
+            _call(_sm_agg_fwd, _ptr(v), _ptr(logit), _ptr(out), _ptr(sm), B * M, K, C, J, _stream(dev))
+        ctx.save_for_backward(v, sm)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        v, sm = ctx.saved_tensors
+        B, M, K, C = v.shape
+        J = sm.shape[-1]
+        dev = v.device
+        dv, dl = torch.empty_like(v), torch.empty_like(sm)
+        with _guard(dev):
+            _call(_sm_agg_bwd, _ptr(dout.contiguous()), _ptr(v), _ptr(sm), _ptr(dv), _ptr(dl), B * M, K, C, J, _stream(dev))
+        return dv, dl
+
+
+def softmax_aggregate(v, logit):
+    """out[b,m,c] = sum_k v[b,m,k,c] * softmax_k(logit)[b,m,k,c % J]   (PointTransformerLayer, layers.py:519-527)."""
+    _floats(v=v.contiguous(), logit=logit.contiguous())
+    if v.dim() != 4 or logit.dim() != 4 or v.shape[:3] != logit.shape[:3] or v.shape[3] % logit.shape[3] != 0:
+        raise RuntimeError('softmax_aggregate: expected v [B,M,K,C] and logit [B,M,K,J] with J dividing C')
+    return _SoftmaxAggregate.apply(v, logit)
+
+
+class _QKScore(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, key, scale):
+        q, key = q.contiguous(), key.contiguous()
+        B, N, K, H, D = q.shape
+        dev = q.device
+        score = torch.empty(B, N, K, H, dtype=torch.float32, device=dev)
+        with _guard(dev):
+            _call(_qk_fwd, _ptr(q), _ptr(key), _ptr(score), B * N, K, H, D, float(scale), _stream(dev))
+        ctx.save_for_backward(q, key, score)
+        ctx.scale = float(scale)
+        return score
+
+    @staticmethod
+    def backward(ctx, ds):
+        q, key, score = ctx.saved_tensors
+        B, N, K, H, D = q.shape
+        dev = q.device
+        dq, dkey = torch.empty_like(q), torch.empty_like(key)
+        with _guard(dev):
+            _call(_qk_bwd, _ptr(ds.contiguous()), _ptr(score), _ptr(q), _ptr(key), _ptr(dq), _ptr(dkey), B * N, K, H, D, ctx.scale,
+                  _stream(dev))
+        return dq, dkey, None
+
+
+def qk_score(q, key, scale):
+    """sigmoid(scale * <q[b,n,k,h,:], key[b,n,h,:]>) -> [B,N,K,H]   (MultiHeadGuidanceQK, layers.py:100-114)."""
+    _floats(q=q.contiguous(), key=key.contiguous())
+    return _QKScore.apply(q, key, scale)
+
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x = x.contiguous()
+        C = x.shape[-1]
+        R = x.numel() // C
+        dev = x.device
+        y = torch.empty_like(x)
+        mean = torch.empty(R, dtype=torch.float32, device=dev)
+        rstd = torch.empty(R, dtype=torch.float32, device=dev)
+        with _guard(dev):
+            _call(_ln_fwd, _ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd), R, C, float(eps), _stream(dev))
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        C = x.shape[-1]
+        R = x.numel() // C
+        dev = x.device
+        dx = torch.empty_like(x)
+        dg, db = torch.empty_like(gamma), torch.empty_like(gamma)
+        nbytes = _ln_bwd_ws(R, C)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        with _guard(dev):
+            _call(_ln_bwd, _ptr(dy.contiguous()), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dg), _ptr(db), R, C,
+                  ws.data_ptr(), nbytes, _stream(dev))
+        return dx, dg, db, None
+
+
+def layer_norm(x, ln):
+    """ln(x) for an nn.LayerNorm over the last axis (elementwise_affine), on HIP."""
+    _floats(x=x.contiguous())
+    if len(ln.normalized_shape) != 1 or ln.normalized_shape[0] != x.shape[-1] or ln.weight is None or ln.bias is None:
+        raise RuntimeError('layer_norm: LayerNorm over the last axis with affine parameters expected')
+    return _LayerNorm.apply(x, ln.weight, ln.bias, ln.eps)

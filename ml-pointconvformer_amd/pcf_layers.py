@@ -243,7 +243,10 @@ class MultiHeadGuidance(pcf_fused.CounterScope):
         return isinstance(self.layer_norm_q, nn.LayerNorm)
 
     def forward(self, guidance_query, guidance_key):
-        return self.forward_diff(self.layer_norm_q(guidance_query) - self.layer_norm_k(guidance_key))
+        if self.layer_norm:        # LayerNorm on the query and on the key (layers.py:52-53), on HIP
+            guidance_query = pcf_fused.layer_norm(guidance_query, self.layer_norm_q)
+            guidance_key = pcf_fused.layer_norm(guidance_key, self.layer_norm_k)
+        return self.forward_diff(guidance_query - guidance_key)
 
     def forward_split(self, guidance_x, nei_inds, feat_pe):
         """Scores for SELF neighbourhoods (key = neighbour 0) without forming the query tensor.
@@ -278,7 +281,7 @@ class MultiHeadGuidanceQK(pcf_fused.CounterScope):
     uses (layers.py:77-114; selected by cfg.attention_type != 'subtraction', :264-269).  The same Linear_BN runs over
     the query tensor and over the key tensor repeated K times (two BatchNorm calls, each with its own batch statistics,
     exactly as upstream); both go through the contraction + column-BatchNorm kernels, the per-head dot product and
-    the sigmoid are element-wise torch ops."""
+    the sigmoid are one HIP kernel (csrc/attention_ops.hip)."""
 
     def __init__(self, cfg, num_heads: int, num_hiddens: int, key_dim: int):
         super().__init__()
@@ -293,8 +296,8 @@ class MultiHeadGuidanceQK(pcf_fused.CounterScope):
         if k.shape[2] != K:
             k = k.expand(-1, -1, K, -1)
         qq = self.qk_linear(q.contiguous()).view(B, N, K, self.num_heads, -1)
-        kk = self.qk_linear(k.contiguous()).view(B, N, K, self.num_heads, -1)[:, :, :1]
-        return torch.sigmoid((qq * kk).sum(-1) * self.scale)
+        kk = self.qk_linear(k.contiguous()).view(B, N, K, self.num_heads, -1)[:, :, 0]
+        return pcf_fused.qk_score(qq, kk, self.scale)          # per-head dot product + sigmoid in one kernel
 
 
 class WeightNet(pcf_fused.CounterScope):
@@ -491,8 +494,8 @@ class PointTransformerLayer(pcf_fused.CounterScope):
     """PointTransformer block, the reference's ablation against PCFLayer (layers.py:419-539; selected by
     cfg.transformer_type != 'PCF', model_architecture.py:138-176): vector attention over the K neighbours with a
     softmax, positional term from the coordinate offsets.  Same sub-module names as upstream (state_dicts load
-    unchanged).  Linears, BatchNorms, gathers and the coordinate offsets run on the HIP kernels of the hot path; the
-    softmax over K and the weighted sum are torch ops (this block is not on any BASELINE config's path)."""
+    unchanged).  Linears, BatchNorms, gathers and the coordinate offsets run on the HIP kernels of the hot path, the
+    softmax over K and the weighted neighbour sum on csrc/attention_ops.hip (this block is not on any BASELINE config's path)."""
 
     def __init__(self, in_planes, out_planes, share_planes=8):
         super().__init__()
@@ -525,9 +528,8 @@ class PointTransformerLayer(pcf_fused.CounterScope):
         w = feats_k - feats_q + dxyz.view(B, M, K, self.out_planes // self.mid_planes, self.mid_planes).sum(3)
         w = pcf_fused.bn_act(w, self.bn_w, pcf_fused.ACT_RELU, self.training)        # BatchNorm1d over (M, K) + the first ReLU
         w = _linear_act(self.linear_w[3], self.linear_w[1](w, pcf_fused.ACT_RELU), pcf_fused.ACT_NONE)
-        w = torch.softmax(w, dim=2)                                                   # over the K neighbours
-        s, c = self.share_planes, self.out_planes
-        new_feats = ((feats_v + dxyz).view(B, M, K, s, c // s) * w.unsqueeze(3)).sum(2).view(B, M, c)
+        # softmax over the K neighbours and the weighted neighbour sum (share_planes groups share a weight) in one kernel
+        new_feats = pcf_fused.softmax_aggregate(feats_v + dxyz, w)
         sparse_feats = pcf_fused.gather_max(feats, nei_ind) if strided else feats
         return F.leaky_relu(new_feats + self.unary_shortcut(sparse_feats), 0.1)
 

@@ -501,3 +501,62 @@ def test_knn_grid_bit_exact_vs_c_oracle_80k(device):
     sub = np.arange(0, 80000, 16)                       # every 16th query keeps the oracle at seconds
     want = knn_c.knn_packed(ref, ref[sub], [0, 80000], [0, len(sub)], 16)
     np.testing.assert_array_equal(got.cpu().numpy()[sub], want)
+
+
+# ---- attention arithmetic of the ablation layers (csrc/attention_ops.hip) against plain torch ------------------------
+@pytest.mark.parametrize('B,M,K,C,J', [(1, 300, 16, 64, 8), (2, 77, 5, 48, 48), (1, 50, 64, 32, 4)])
+def test_softmax_aggregate_against_torch(device, B, M, K, C, J):
+    import pcf_fused
+    g = torch.Generator().manual_seed(B * 1000 + M)
+    v = torch.randn(B, M, K, C, generator=g).to(device).requires_grad_(True)
+    lg = (torch.randn(B, M, K, J, generator=g) * 2).to(device).requires_grad_(True)
+    out = pcf_fused.softmax_aggregate(v, lg)
+    up = torch.randn(B, M, C, generator=g).to(device)
+    out.backward(up)
+    vr, lr = v.detach().clone().requires_grad_(True), lg.detach().clone().requires_grad_(True)
+    w = torch.softmax(lr, dim=2)
+    want = (vr.view(B, M, K, C // J, J) * w.unsqueeze(3)).sum(2).view(B, M, C)          # layers.py:523-527
+    want.backward(up)
+    torch.testing.assert_close(out, want, **TOL)
+    torch.testing.assert_close(v.grad, vr.grad, **TOL)
+    torch.testing.assert_close(lg.grad, lr.grad, **TOL)
+
+
+@pytest.mark.parametrize('B,N,K,H,D', [(1, 200, 16, 8, 16), (2, 50, 7, 4, 5)])
+def test_qk_score_against_torch(device, B, N, K, H, D):
+    import pcf_fused
+    g = torch.Generator().manual_seed(N)
+    q = torch.randn(B, N, K, H, D, generator=g).to(device).requires_grad_(True)
+    key = torch.randn(B, N, H, D, generator=g).to(device).requires_grad_(True)
+    s = pcf_fused.qk_score(q, key, D ** -0.5)
+    up = torch.randn(B, N, K, H, generator=g).to(device)
+    s.backward(up)
+    qr, kr = q.detach().clone().requires_grad_(True), key.detach().clone().requires_grad_(True)
+    want = torch.sigmoid((qr * kr[:, :, None]).sum(-1) * D ** -0.5)                     # layers.py:108-113
+    want.backward(up)
+    torch.testing.assert_close(s, want, **TOL)
+    torch.testing.assert_close(q.grad, qr.grad, **TOL)
+    torch.testing.assert_close(key.grad, kr.grad, **TOL)
+
+
+@pytest.mark.parametrize('shape,C', [((1, 500, 16), 64), ((3, 41), 20), ((1, 9000), 130)])
+def test_layer_norm_against_torch(device, shape, C):
+    import pcf_fused
+    g = torch.Generator().manual_seed(C)
+    ln = torch.nn.LayerNorm(C).to(device)
+    with torch.no_grad():
+        ln.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        ln.bias.copy_(torch.randn(C, generator=g))
+    x = (torch.randn(*shape, C, generator=g) * 3 + 1).to(device).requires_grad_(True)
+    y = pcf_fused.layer_norm(x, ln)
+    up = torch.randn(*shape, C, generator=g).to(device)
+    y.backward(up)
+    got = (x.grad.clone(), ln.weight.grad.clone(), ln.bias.grad.clone())
+    ln.zero_grad()
+    xr = x.detach().clone().requires_grad_(True)
+    want = ln(xr)
+    want.backward(up)
+    torch.testing.assert_close(y, want, **TOL)
+    torch.testing.assert_close(got[0], xr.grad, **TOL)
+    torch.testing.assert_close(got[1], ln.weight.grad, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(got[2], ln.bias.grad, rtol=1e-3, atol=1e-3)
