@@ -179,7 +179,8 @@ def bench_train(args):
     torch.manual_seed(1)
     net = pcf_model.PointConvFormer_Segmentation(cfg).to(dev).train()
     model = pcf_dist.wrap_ddp(net, dev)
-    opt = pcf_train.make_optimizer(cfg, net)
+    use_graph = world == 1 and not args.no_graph
+    opt = pcf_train.make_optimizer(cfg, net, capturable=use_graph)
     crit = torch.nn.CrossEntropyLoss(ignore_index=cfg.ignore_label, label_smoothing=cfg.label_smoothing).to(dev)
     # a small pool of distinct packed batches, rotated, so the kNN / CSR work is real every step
     pool = []
@@ -189,17 +190,42 @@ def bench_train(args):
         pool.append(pcf_train.pack_batch(scenes, cfg.grid_size))
     n_pts = sum(pool[0][4][0])
 
-    def step(i):
+    def eager(i):
         return pcf_train.training_iteration(model, opt, crit, cfg, pool[i % len(pool)])
 
+    step, graphed = eager, False
     for i in range(args.warmup):
-        step(i)
+        eager(i)
+    if use_graph:
+        # one HIP graph per pooled batch: the ~2000 launches of an iteration replayed with one host call each
+        try:
+            gstep = pcf_train.GraphedTrainingStep(model, opt, crit, cfg)
+            for i in range(len(pool)):
+                gstep(pool[i])
+            torch.cuda.synchronize()
+            step, graphed = (lambda i: gstep(pool[i % len(pool)])), True
+            for i in range(2 * len(pool)):
+                step(i)
+        except Exception as exc:       # capture is an optimisation of the host side, not a requirement
+            if args.graph:
+                raise
+            print(f'bench: HIP-graph capture of the training iteration failed ({type(exc).__name__}: {exc}); timing eager '
+                  'iterations', file=sys.stderr)
+            step, graphed = eager, False
     pcf_dist.fence(dev)
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(i)
     pcf_dist.fence(dev)
     elapsed = pcf_dist.max_over_ranks(time.perf_counter() - t0, dev)
+    eager_ms = None
+    if graphed:
+        pcf_dist.fence(dev)
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            eager(i)
+        pcf_dist.fence(dev)
+        eager_ms = (time.perf_counter() - t0) / args.steps * 1e3
     if rank == 0:
         print(json.dumps({
             'metric': f'{args.model} train iters/sec, synthetic scenes', 'value': round(args.steps / elapsed, 3),
@@ -207,6 +233,9 @@ def bench_train(args):
             'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'points_per_s': round(world * n_pts * args.steps / elapsed, 1), 'final_loss': round(float(loss), 4),
+            'hip_graph': graphed, 'eager_ms_per_step': None if eager_ms is None else round(eager_ms, 3),
+            'collective_backend': None if world == 1 else dist.get_backend(), 'world_size': world,
+            'step_path': 'HIP-graph replay per packed batch' if graphed else ('eager launches' + ('' if world == 1 else ' under DistributedDataParallel')),
             'config': {'workload': f'{args.model} model ({sum(p.numel() for p in net.parameters())} params), '
                                    f'{args.scenes} scenes x ~{args.points} points per GPU per iteration '
                                    f'({n_pts} level-0 points, levels {pool[0][4]}), kNN + CSR + fwd + bwd + AdamW',

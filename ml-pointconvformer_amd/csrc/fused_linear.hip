@@ -199,6 +199,7 @@ __device__ __forceinline__ bool column_totals(float s1, float s2, int n0, int N,
     __syncthreads();
     if (!s_last) return false;
     observe();
+    float gsum = 0.f;
     if (mine) {
         const float* p = part + ((size_t)(grp * FL_GROUP) * 2 + which) * N + col;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -208,9 +209,15 @@ __device__ __forceinline__ bool column_totals(float s1, float s2, int n0, int N,
             a2 += ld_agent(p + (size_t)(i + 2) * 2 * N); a3 += ld_agent(p + (size_t)(i + 3) * 2 * N);
         }
         for (; i < gsize; ++i) a0 += ld_agent(p + (size_t)i * 2 * N);
-        st_agent(gpart + ((size_t)grp * 2 + which) * N + col, (a0 + a1) + (a2 + a3));
+        gsum = (a0 + a1) + (a2 + a3);
     }
     if (threadIdx.x == 0) t1[grp] = 0;
+    if (groups == 1) {                              // small problems: one level, one ticket
+        if (threadIdx.x < 2 * BN) sh_tot[which][cl] = (double)gsum;
+        __syncthreads();
+        return true;
+    }
+    if (mine) st_agent(gpart + ((size_t)grp * 2 + which) * N + col, gsum);
     publish();
     __syncthreads();
     if (threadIdx.x == 0) s_last = (atomicAdd(&t1[FL_MAXG], 1) == groups - 1) ? 1 : 0;

@@ -43,10 +43,22 @@ def _as_device_points(p):
     return p.reshape(-1, 3).contiguous()
 
 
+_OFFSET_CACHE = {}
+
+
 def _offsets(counts, dev):
-    off = np.zeros(len(counts) + 1, np.int32)
-    np.cumsum(counts, out=off[1:])
-    return off, torch.from_numpy(off).to(dev, non_blocking=True)
+    """(host int32 prefix offsets, the same on `dev`) of per-sample counts.  The device copy is cached per (counts,
+    device): a training loop asks for the same few tables every iteration, and a cached table needs no host-to-device
+    copy inside a HIP-graph capture."""
+    key = (tuple(int(c) for c in counts), dev)
+    hit = _OFFSET_CACHE.get(key)
+    if hit is None:
+        off = np.zeros(len(counts) + 1, np.int32)
+        np.cumsum(counts, out=off[1:])
+        if len(_OFFSET_CACHE) > 4096:
+            _OFFSET_CACHE.clear()
+        hit = _OFFSET_CACHE[key] = (off, torch.from_numpy(off).to(dev))
+    return hit
 
 
 def _random_fallback(idx, ref_counts, qry_off, K):

@@ -105,13 +105,14 @@ def build_edges(cfg, pointclouds, points_stored):
     return es, ef, ep, inv
 
 
-def make_optimizer(cfg, model):
+def make_optimizer(cfg, model, capturable=False):
     """AdamW as the training script builds it (train_ScanNet_DDP_WarmUP.py:237-241), as ONE multi-tensor kernel per
     step on the GPU (`fused=True`): the default for-each form issues ~115 launches over the 196 parameter tensors and
     costs 5 ms of host time per iteration -- more than the GPU spends on the optimizer."""
     params = list(model.parameters())
     fused = all(p.is_cuda for p in params)
-    return torch.optim.AdamW(params, lr=cfg.learning_rate, weight_decay=cfg.adamw_decay, fused=fused)
+    return torch.optim.AdamW(params, lr=cfg.learning_rate, weight_decay=cfg.adamw_decay, fused=fused,
+                             capturable=bool(capturable and fused))
 
 
 @torch.no_grad()
@@ -138,3 +139,43 @@ def training_iteration(model, optimizer, criterion, cfg, batch, edges=None):
     optimizer.step()
     optimizer.zero_grad(set_to_none=True)
     return loss.detach()
+
+
+class GraphedTrainingStep:
+    """training_iteration captured in a HIP graph per packed batch (one graph per distinct batch object) and replayed:
+    the ~2000 kernel launches of an iteration -- kNN, CSR, forward, loss, backward, clipping, AdamW -- cost one host call.
+
+    The whole iteration is device-side (no host reads: the kNN engines are chosen from host-known sizes, offsets tables
+    are cached device tensors, the optimizer is built with capturable=True so its step counters live on the device).
+    A graph is tied to the shapes of its batch: this serves loops that revisit a fixed set of packed batches (the
+    benchmark's rotating pool); batches of new shapes fall back to a fresh capture.  Replaying changes parameters,
+    optimizer state and BatchNorm running statistics exactly as the eager iteration does."""
+
+    def __init__(self, model, optimizer, criterion, cfg, warmup=2):
+        self.model, self.optimizer, self.criterion, self.cfg, self.warmup = model, optimizer, criterion, cfg, warmup
+        self.graphs = {}
+        self.pool = None
+
+    def _capture(self, batch):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):          # warm-up off the capture: allocator pools, lazy kernel loading, persistent buffers
+            for _ in range(self.warmup):
+                training_iteration(self.model, self.optimizer, self.criterion, self.cfg, batch)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=self.pool):
+            loss = training_iteration(self.model, self.optimizer, self.criterion, self.cfg, batch)
+        if self.pool is None:
+            self.pool = g.pool()
+        return g, loss
+
+    def __call__(self, batch):
+        key = id(batch)
+        hit = self.graphs.get(key)
+        if hit is None:
+            hit = self.graphs[key] = self._capture(batch) + (batch,)       # keep the batch alive: the graph reads its tensors
+            return hit[1]
+        hit[0].replay()
+        return hit[1]
