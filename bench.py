@@ -15,12 +15,13 @@ cloud (the per-scene operator does not shard) under DistributedDat
 collective is the gradient all-reduce over RCCL.  value = points processed by all ranks / wall time.
 
 On one GPU the timed steps are replays of a HIP graph captured from one eager step (same kernels, same order;
-``"hip_graph": true``; ``--no-graph`` times eager steps, which are marginally host-bound at ~190 launches per
-1.6 ms); with N > 1 the steps are eager.
+``"hip_graph": true``; ``eager_ms_per_step`` is the same loop without the graph); with N > 1 the steps are eager under
+DistributedDataParallel (``--graph``: replayed steps + one flat-bucket RCCL all-reduce).
 
-Also reported on the one JSON line: ``roofline`` for the dominant hand-written kernel (HIP events
-around its launches inside the timed region) and ``cpu_baseline`` (the oracle's CPU restatement of the
-same layer, timed on this host; rank 0, 1 GPU only).
+Also reported on the one JSON line: ``roofline`` for the entry point with the largest device time per step (HIP events
+around every entry point of eager steps; flops-based for the MFMA-bound edge graph, bytes-based for the aggregate),
+``roofline_gather`` for the aggregate (north_star's gather/scatter phase), ``whole_step`` fractions, and ``cpu_baseline``
+(the oracle's CPU restatement of the same layer on all host cores, plus the N = 4096 PointConv line; rank 0, 1 GPU only).
 """
 import argparse
 import json
@@ -71,10 +72,28 @@ def synth_cloud(n, seed):
 
 
 def _host_cores():
+    """CPU cores this process may actually use: the affinity mask capped by the cgroup CPU quota (a 1-GPU box exposes all
+    256 hardware threads in the mask but grants 16 cores of CPU time; 256 torch threads on 16 cores thrash: 56 s per
+    iteration instead of 2)."""
     try:
-        return len(os.sched_getaffinity(0))
+        cores = len(os.sched_getaffinity(0))
     except AttributeError:
-        return os.cpu_count() or 1
+        cores = os.cpu_count() or 1
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            txt = open(path).read().split()
+            if path.endswith('cpu.max'):
+                if txt[0] != 'max':
+                    cores = min(cores, max(1, -(-int(txt[0]) // int(txt[1]))))
+            else:
+                quota = int(txt[0])
+                period = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+                if quota > 0:
+                    cores = min(cores, max(1, -(-quota // period)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, cores)
 
 
 def _cpu_model():
@@ -106,7 +125,10 @@ def cpu_baseline(state_dict, xyz, nrm, feats, idx, iters=5):
             v.grad = None
         f.grad = None
 
+    t0 = time.perf_counter()
     step()
+    warm = time.perf_counter() - t0
+    iters = max(1, min(iters, int(40.0 / max(warm, 1e-3))))        # bounded sample: at most ~40 s of CPU work
     ts = []
     for _ in range(iters):
         t0 = time.perf_counter()
@@ -117,7 +139,8 @@ def cpu_baseline(state_dict, xyz, nrm, feats, idx, iters=5):
     return {'value': round(xyz.shape[1] / med, 1), 'unit': 'points/s', 'cores': torch.get_num_threads(),
             'kind': 'port', 'cpu': _cpu_model(),
             'sample': f'full workload N={xyz.shape[1]} K={idx.shape[2]}, 1 warm-up + {iters} timed iterations, median '
-            f'{med * 1e3:.0f} ms; oracle/pcf_oracle.py:pcf_layer on torch CPU, all {cores} cores of the process affinity mask'}
+            f'{med * 1e3:.0f} ms; oracle/pcf_oracle.py:pcf_layer on torch CPU, all {cores} cores of the process CPU allowance '
+            f'(affinity mask capped by the cgroup quota)'}
 
 
 def cpu_baseline_pointconv(iters=5, n=4096, k=16):
@@ -352,8 +375,8 @@ def main():
                          'the eager step is marginally host-bound -- ~190 launches in 1.6 ms -- and slows down by '
                          '5-15 %% in the first process of a fresh box)')
     ap.add_argument('--graph', action='store_true',
-                    help='capture one step (forward+backward) in a HIP graph and time replays (1 GPU); the roofline '
-                         'kernel is then timed in eager steps right after the timed region')
+                    help='insist on HIP-graph replay (a failed capture is an error instead of a fall-back); with N > 1 GPUs: '
+                         'replayed steps + one flat-bucket all-reduce instead of eager steps under DistributedDataParallel')
     ap.add_argument('--deterministic', action='store_true',
                     help='grad_x by CSR gather-reduce (bitwise reproducible) instead of float atomics')
     args = ap.parse_args()
@@ -408,7 +431,9 @@ def main():
     params = list(layer.parameters())        # walking the module tree every step costs ~0.1 ms of host time
     # N > 1: one flat bucket of the 13.7 k gradient floats, packed inside the replayed graph, one RCCL all-reduce and
     # one multi-tensor copy back per step (DDP's per-step hooks need eager launches: ~20 % slower steps)
-    bucket = pcf_dist.GradBucket(params, list(layer.buffers())) if (world > 1 and not args.no_graph) else None
+    # N > 1 default: eager steps under DistributedDataParallel -- the path that is standard and has met RCCL; the replayed
+    # graph + flat bucket (three host calls per step) is opt-in with --graph until it has been run on a multi-GPU node
+    bucket = pcf_dist.GradBucket(params, list(layer.buffers())) if (world > 1 and args.graph and not args.no_graph) else None
     if bucket is not None:
         bucket.broadcast_parameters()
     elif world > 1:
