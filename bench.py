@@ -202,7 +202,9 @@ def bench_train(args):
     torch.manual_seed(1)
     net = pcf_model.PointConvFormer_Segmentation(cfg).to(dev).train()
     model = pcf_dist.wrap_ddp(net, dev)
-    use_graph = world == 1 and not args.no_graph
+    # configPCF_2cm_PTF2 (generic C_mid = 3 decoder kernels, stochastic depth) is timed eagerly: its captured iteration
+    # hit a GPU memory fault on replay that is not understood yet (the eager iteration and all its tests pass)
+    use_graph = world == 1 and not args.no_graph and (args.graph or (cfg.drop_path_rate == 0 and cfg.mid_dim_back == 1))
     opt = pcf_train.make_optimizer(cfg, net, capturable=use_graph)
     crit = torch.nn.CrossEntropyLoss(ignore_index=cfg.ignore_label, label_smoothing=cfg.label_smoothing).to(dev)
     # a small pool of distinct packed batches, rotated, so the kNN / CSR work is real every step
@@ -594,8 +596,8 @@ def main():
         gather = max((k for k in ('pcf_hip_pcf_forward', 'pcf_hip_pcf_backward', 'pcf_hip_pcf_backward_csr') if k in hip_ms),
                      key=lambda k: hip_ms[k])
         roofline_gather = block(gather, hip_ms[gather])
-        try:       # HBM bytes per launch from the PMC counters (profiles/r01h_pmc_traffic.json), same shape only
-            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01h_pmc_traffic.json')))
+        try:       # HBM bytes per launch from the PMC counters (profiles/r02_pmc_traffic.json), same shape only
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')))
             if pmc['shape'] == {'N': n, 'K': K_NEI, 'Ci': Ci, 'Cm': C_MID, 'H': HEADS}:
                 roofline_gather['traffic'] = pmc['kernels'].get(cand[gather][2].split(' ')[0], {}).get('traffic_bytes')
         except (OSError, ValueError, KeyError):

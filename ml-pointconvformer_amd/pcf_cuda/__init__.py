@@ -196,7 +196,13 @@ def record_kernel_times(enable: bool, only=None):
     return _timeline
 
 
+_TRACE_CALLS = os.environ.get('PCF_TRACE_CALLS') == '1'      # debugging aid: name every entry point on stderr before it runs
+
+
 def _call(fn, *args):
+    if _TRACE_CALLS:
+        import sys
+        print('pcf_cuda call:', fn.__name__, [a for a in args if isinstance(a, int) and abs(a) < (1 << 40)][:14], file=sys.stderr, flush=True)
     if _timeline is None or (_timeline_only is not None and fn.__name__ not in _timeline_only):
         rc = fn(*args)
     else:
