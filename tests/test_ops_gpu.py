@@ -560,3 +560,95 @@ def test_layer_norm_against_torch(device, shape, C):
     torch.testing.assert_close(got[0], xr.grad, **TOL)
     torch.testing.assert_close(got[1], ln.weight.grad, rtol=1e-3, atol=1e-3)
     torch.testing.assert_close(got[2], ln.bias.grad, rtol=1e-3, atol=1e-3)
+
+
+# ---- point-level Linear + BatchNorm chain kernels (csrc/fused_linear.hip) against torch autograd ---------------------
+def _torch_chain(x, W1, b1, g1, be1, W2, b2, g2, be2, res, act1, act2, eps=1e-5):
+    """y = act2(BN2(act1(BN1(x W1^T + b1)) W2^T + b2) + res) with batch statistics, in float64."""
+    import torch.nn.functional as F
+    acts = {0: lambda t: t, 1: F.relu, 2: lambda t: F.leaky_relu(t, 0.1), 3: torch.sigmoid}
+
+    def bn(z, g, b):
+        return (z - z.mean(0)) * torch.rsqrt(z.var(0, unbiased=False) + eps) * g + b
+
+    z1 = x @ W1.t() + b1
+    y1 = acts[act1](bn(z1, g1, be1))
+    z2 = y1 @ W2.t() + b2
+    return acts[act2](bn(z2, g2, be2) + res), z1, z2
+
+
+@pytest.mark.parametrize('R,C0,C1,C2,act1,act2', [(5000, 64, 16, 32, 2, 0), (777, 256, 32, 64, 1, 2), (1300, 6, 20, 70, 2, 2),
+                                                  (33, 16, 8, 8, 1, 1), (3000, 96, 48, 192, 1, 2)])
+def test_fused_linear_chain_kernels_against_torch(device, R, C0, C1, C2, act1, act2):
+    """Two chained Linear+BatchNorm layers through the four C-ABI entry points (forward with the producer's BatchNorm in the
+    A-tile loader and a side output, top-of-chain statistics, dz-prologue input / weight gradients with the producer's
+    statistics in the epilogue): outputs, running statistics, input gradient and all parameter gradients against float64
+    torch autograd, 1e-3 of the scale."""
+    import pcf_fused as PF
+    g = torch.Generator().manual_seed(R + C2)
+    r = lambda *s: torch.randn(*s, generator=g)
+    x, W1, b1, W2, b2 = r(R, C0), r(C1, C0) / C0 ** 0.5, r(C1) * 0.1, r(C2, C1) / C1 ** 0.5, r(C2) * 0.1
+    g1, be1, g2, be2, res, up = torch.rand(C1, generator=g) + 0.5, r(C1) * 0.2, torch.rand(C2, generator=g) + 0.5, r(C2) * 0.2, r(R, C2), r(R, C2)
+    d = lambda t: t.to(device).contiguous()
+    bn1, bn2 = torch.nn.BatchNorm1d(C1).to(device), torch.nn.BatchNorm1d(C2).to(device)
+    with torch.no_grad():
+        bn1.weight.copy_(g1); bn1.bias.copy_(be1); bn2.weight.copy_(g2); bn2.bias.copy_(be2)
+    dev = device
+    s = PF._stream(dev)
+    xd, W1d, b1d, W2d, b2d, resd, upd = d(x), d(W1), d(b1), d(W2), d(b2), d(res), d(up)
+    with PF._guard(dev):
+        z1, cst1 = PF._flin_forward(xd, None, 0, None, W1d, b1d, bn1, 0.1, s, dev)
+        y1 = torch.empty(R, C1, device=dev)
+        z2, cst2 = PF._flin_forward(z1, cst1, act1, y1, W2d, b2d, bn2, 0.1, s, dev)
+        out = torch.empty_like(z2)
+        PF._call(PF._bnact_fwd, PF._ptr(z2), PF._ptr(resd), R, C2, cst2[2].data_ptr(), cst2[3].data_ptr(), PF._ptr(bn2.weight),
+                 PF._ptr(bn2.bias), act2, PF._ptr(out), s)
+        # backward
+        f32 = dict(dtype=torch.float32, device=dev)
+        dg2, dbe2, db2 = torch.empty(C2, **f32), torch.empty(C2, **f32), torch.empty(C2, **f32)
+        dg1, dbe1, db1 = torch.empty(C1, **f32), torch.empty(C1, **f32), torch.empty(C1, **f32)
+        gg = torch.empty_like(z2)
+        ws, nbytes = PF._ws(dev, R, C2, C2)
+        PF._call(PF._bn_bwd_stats, PF._ptr(upd), PF._ptr(z2), PF._ptr(resd), PF._ptr(cst2), act2, R, C2, PF._ptr(gg), PF._ptr(dg2),
+                 PF._ptr(dbe2), PF._ptr(db2), ws.data_ptr(), nbytes, PF._tickets(dev).data_ptr(), s)
+        wg = PF._WeightGrads(dev, s)
+        dW2 = wg.add(gg, z2, cst2, 0, z1, cst1, act1)
+        dy1 = PF._flin_bwd_input(gg, z2, cst2, 0, W2d, None, z1, cst1, act1, (dg1, dbe1, db1), s, dev)
+        dW1 = wg.add(dy1, z1, cst1, act1, xd, None, 0)
+        dx = PF._flin_bwd_input(dy1, z1, cst1, act1, W1d, None, None, None, 0, None, s, dev)
+        wg.finish()
+    t = lambda v: v.double().requires_grad_(True)
+    X, A1, B1, G1, E1, A2, B2, G2, E2, RS = t(x), t(W1), t(b1), t(g1), t(be1), t(W2), t(b2), t(g2), t(be2), t(res)
+    want, rz1, rz2 = _torch_chain(X, A1, B1, G1, E1, A2, B2, G2, E2, RS, act1, act2)
+    want.backward(up.double())
+
+    def close(got, ref, what, tol=1e-3):
+        ref = ref.float()
+        torch.testing.assert_close(got.cpu(), ref, rtol=tol, atol=tol * max(1.0, float(ref.abs().max())), msg=lambda m: f'{what}: {m}')
+
+    close(z1, rz1.detach(), 'z1'); close(z2, rz2.detach(), 'z2'); close(out, want.detach(), 'out')
+    acts = {0: lambda v: v, 1: torch.relu, 2: lambda v: torch.nn.functional.leaky_relu(v, 0.1), 3: torch.sigmoid}
+    z1d = rz1.detach()
+    close(y1, acts[act1]((z1d - z1d.mean(0)) * torch.rsqrt(z1d.var(0, unbiased=False) + 1e-5) * g1.double() + be1.double()), 'side output')
+    close(bn1.running_mean, 0.1 * z1d.mean(0), 'running_mean 1')
+    close(bn2.running_var, 0.9 + 0.1 * rz2.detach().var(0, unbiased=True), 'running_var 2')
+    close(gg, RS.grad, 'g (= residual gradient)')
+    close(dx, X.grad, 'dx'); close(dW1, A1.grad, 'dW1'); close(dW2, A2.grad, 'dW2')
+    close(dg1, G1.grad, 'dgamma1'); close(dbe1, E1.grad, 'dbeta1'); close(dg2, G2.grad, 'dgamma2'); close(dbe2, E2.grad, 'dbeta2')
+    assert float(db1.abs().max()) == 0.0 and float(db2.abs().max()) == 0.0          # bias in front of a batch-statistics BatchNorm
+    assert float(PF._tickets(dev).abs().sum()) == 0.0                                 # the kernels leave their tickets zeroed
+
+
+def test_fused_linear_rejects_bad_arguments(device):
+    import pcf_fused as PF
+    dev = device
+    x = torch.randn(10, 8, device=dev)
+    W = torch.randn(4, 8, device=dev)
+    bn = torch.nn.BatchNorm1d(4).to(dev)
+    with pytest.raises(RuntimeError, match='workspace|statistics'):
+        PF._call(PF._flin_fwd, PF._ptr(x), 10, 8, None, 0, None, PF._ptr(W), None, 4, PF._ptr(torch.empty(10, 4, device=dev)),
+                 PF._ptr(torch.empty(6, 4, device=dev)), PF._ptr(bn.weight), PF._ptr(bn.bias), None, None, 1e-5, 0.1, None, 0, None,
+                 PF._stream(dev))
+    # zero rows: nothing to do, no launch
+    z, cst = PF._flin_forward(torch.empty(0, 8, device=dev), None, 0, None, W, None, None, 0.0, PF._stream(dev), dev)
+    assert z.shape == (0, 4)
