@@ -103,6 +103,42 @@ int pcf_hip_bn_backward_stats(const float* dy, const float* z, const float* res,
                               float* g, float* dgamma, float* dbeta, float* dbias, void* workspace, size_t workspace_bytes, int* tickets,
                               void* stream);
 
+/* ---- PCFLayer point-level layers as row chains (narrow widths) ------------------------------------------------------
+ * The head of a PCFLayer -- unary1 (Linear+BN+LeakyReLU, layers.py:335), guidance_unary (Linear+BN, :369) and the gathered
+ * half of the first guidance layer (u = guidance_x Wa^T) -- in three passes forward and three backward that keep every
+ * intermediate of a 16-row tile in registers (weights and BatchNorm constants in LDS); see csrc/point_chain.hip.
+ * x [R,c_in] -> z1 [R,mid] (raw unary1 output, kept for the backward), fx [R,mid], u [R,8]; records cst1 [6][mid], cst2 [6][g]
+ * as in the flin_* entry points.  `tickets`: one zero int the kernels leave zeroed.  _supported(): widths instantiated. */
+int pcf_hip_point_head_supported(int c_in, int mid, int g);
+size_t pcf_hip_point_head_workspace_bytes(long long R, int c_in, int mid, int g);
+int pcf_hip_point_head_forward(const float* x, long long R, int c_in, int mid, int g, const float* W1, const float* b1,
+                               const float* gamma1, const float* beta1, float* rmean1, float* rvar1, float mom1, const float* W2,
+                               const float* b2, const float* gamma2, const float* beta2, float* rmean2, float* rvar2, float mom2,
+                               const float* Wa, float eps, float* z1, float* fx, float* u, float* cst1, float* cst2, void* workspace,
+                               size_t workspace_bytes, int* tickets, void* stream);
+int pcf_hip_point_head_backward(const float* dfx, const float* du, const float* x, const float* z1, const float* fx, long long R,
+                                int c_in, int mid, int g, const float* W1, const float* W2, const float* b2, const float* Wa,
+                                float* cst1, float* cst2, float* dx, float* dW1, float* db1, float* dgamma1, float* dbeta1,
+                                float* dW2, float* db2, float* dgamma2, float* dbeta2, float* dWa, void* workspace,
+                                size_t workspace_bytes, int* tickets, void* stream);
+
+/* The tail of a PCFLayer -- linear (Linear+BN+ReLU on the aggregate, layers.py:393-394) and unary2 (Linear+BN, :397-400) in
+ * front of the residual sum (:414) -- as row chains: z3 [R,c_half], z4 [R,c_out] raw, records cst3 / cst4.  The final
+ * out = LeakyReLU(BN4(z4) + shortcut) is pcf_hip_bnact_forward_res with mean / rstd = rows 2 / 3 of cst4.  Backward: g4
+ * (the gradient of the shortcut), dagg, dW4, BatchNorm / bias gradients; g3_out receives dy3 masked by the ReLU, from which
+ * the caller takes dW3 = dz3^T agg with pcf_hip_flin_backward_weight_slabs(g3_out, z3, cst3, act 1, agg). */
+int pcf_hip_point_tail_supported(int c_agg, int c_half, int c_out);
+size_t pcf_hip_point_tail_workspace_bytes(long long R, int c_agg, int c_half, int c_out);
+int pcf_hip_point_tail_forward(const float* agg, long long R, int c_agg, int c_half, int c_out, const float* W3, const float* b3,
+                               const float* gamma3, const float* beta3, float* rmean3, float* rvar3, float mom3, const float* W4,
+                               const float* b4, const float* gamma4, const float* beta4, float* rmean4, float* rvar4, float mom4,
+                               float eps, float* z3, float* z4, float* cst3, float* cst4, void* workspace, size_t workspace_bytes,
+                               int* tickets, void* stream);
+int pcf_hip_point_tail_backward(const float* dout, const float* res, const float* z3, const float* z4, long long R, int c_agg,
+                                int c_half, int c_out, const float* W3, const float* W4, float* cst3, float* cst4, float* g4,
+                                float* g3_out, float* dagg, float* dW4, float* db3, float* dgamma3, float* dbeta3, float* db4,
+                                float* dgamma4, float* dbeta4, void* workspace, size_t workspace_bytes, int* tickets, void* stream);
+
 /* ---- attention arithmetic of the ablation layers ------------------------------------------------
  * softmax_aggregate: PointTransformerLayer.forward, layers.py:519-527.  v [R,K,C], logit [R,K,J] (J divides C: the
  *   share_planes groups) -> sm = softmax over K of logit (saved for the backward), out[r,c] = sum_k v[r,k,c] * sm[r,k,c % J].

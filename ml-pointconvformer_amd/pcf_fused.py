@@ -1092,6 +1092,9 @@ def point_head(x, unary1, guidance_unary, Wa):
         l1 = unary1.mlp
         bn1 = l1.bn
         args += [l1.c.weight, l1.c.bias, l1.bn.weight, l1.bn.bias]
+        if bn1.eps == l2.bn.eps and Wa.shape[0] == 8 and \
+                point_head_chain_supported(l1.c.in_features, l1.c.out_features, l2.c.out_features):
+            return _PointHeadChain.apply((bn1, l2.bn), x.contiguous(), *args)      # narrow widths: the row chain
     return _PointHead.apply((bn1, l2.bn), x.contiguous(), *args)
 
 
@@ -1099,7 +1102,10 @@ def point_tail(agg, shortcut, linear, unary2):
     """LeakyReLU(unary2(ReLU(linear(agg))) + shortcut) for two Linear_BN modules (layers.py:393-414)."""
     _floats(agg=agg, shortcut=shortcut)
     l4 = unary2.mlp
-    return _PointTail.apply((linear.bn, l4.bn), agg.contiguous(), shortcut.contiguous(), linear.c.weight, linear.c.bias,
+    fn = _PointTail
+    if linear.bn.eps == l4.bn.eps and point_tail_chain_supported(linear.c.in_features, linear.c.out_features, l4.c.out_features):
+        fn = _PointTailChain                                                     # BASELINE widths: the row chain
+    return fn.apply((linear.bn, l4.bn), agg.contiguous(), shortcut.contiguous(), linear.c.weight, linear.c.bias,
                             linear.bn.weight, linear.bn.bias, l4.c.weight, l4.c.bias, l4.bn.weight, l4.bn.bias)
 
 
@@ -1219,3 +1225,144 @@ def layer_norm(x, ln):
     if len(ln.normalized_shape) != 1 or ln.normalized_shape[0] != x.shape[-1] or ln.weight is None or ln.bias is None:
         raise RuntimeError('layer_norm: LayerNorm over the last axis with affine parameters expected')
     return _LayerNorm.apply(x, ln.weight, ln.bias, ln.eps)
+
+
+# --------------------------------------------------------------------------------------------------
+# PCFLayer head as a row chain on the matrix cores (csrc/point_chain.hip), for the widths it is instantiated for
+# --------------------------------------------------------------------------------------------------
+_ph_ok = _sig('pcf_hip_point_head_supported', [_I, _I, _I])
+_ph_ws = getattr(_lib, 'pcf_hip_point_head_workspace_bytes')
+_ph_ws.argtypes = [_LL, _I, _I, _I]
+_ph_ws.restype = _Z
+_ph_fwd = _sig('pcf_hip_point_head_forward', [_P, _LL, _I, _I, _I, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _F, _P, _F,
+                                              _P, _P, _P, _P, _P, _P, _Z, _P, _P])
+_ph_bwd = _sig('pcf_hip_point_head_backward', [_P, _P, _P, _P, _P, _LL, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                               _P, _P, _P, _P, _Z, _P, _P])
+
+
+def point_head_chain_supported(c_in, mid, g):
+    return bool(_ph_ok(int(c_in), int(mid), int(g)))
+
+
+class _PointHeadChain(torch.autograd.Function):
+    """(fx, u) = head(x) through the three-pass row chain (csrc/point_chain.hip): three launches forward, four backward."""
+
+    @staticmethod
+    def forward(ctx, bns, x, Wa, W2, b2, g2, be2, W1, b1, g1, be1):
+        dev = x.device
+        shape = x.shape
+        x2 = x.reshape(-1, shape[-1])
+        R, cin = x2.shape
+        mid, G = W1.shape[0], W2.shape[0]
+        bn1, bn2 = bns
+        f32 = dict(dtype=torch.float32, device=dev)
+        z1, fx = torch.empty(R, mid, **f32), torch.empty(R, mid, **f32)
+        u = torch.empty(R, Wa.shape[0], **f32)
+        cst1, cst2 = torch.empty(6, mid, **f32), torch.empty(6, G, **f32)
+        nbytes = _ph_ws(R, cin, mid, G)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        m1, m2 = bn_momentum(bn1), bn_momentum(bn2)
+        with _guard(dev):
+            _call(_ph_fwd, _ptr(x2), R, cin, mid, G, _ptr(W1), _ptr(b1), _ptr(g1), _ptr(be1), _ptr(bn1.running_mean),
+                  _ptr(bn1.running_var), float(m1), _ptr(W2), _ptr(b2), _ptr(g2), _ptr(be2), _ptr(bn2.running_mean),
+                  _ptr(bn2.running_var), float(m2), _ptr(Wa), float(bn1.eps), _ptr(z1), _ptr(fx), _ptr(u), _ptr(cst1), _ptr(cst2),
+                  ws.data_ptr(), nbytes, _tickets(dev).data_ptr(), _stream(dev))
+        count_batch(bn1)
+        count_batch(bn2)
+        ctx.save_for_backward(x2, z1, fx, cst1, cst2, Wa, W2, b2, W1)
+        ctx.shape = shape
+        return fx.view(*shape[:-1], mid), u.view(*shape[:-1], u.shape[-1])
+
+    @staticmethod
+    def backward(ctx, dfx, du):
+        x2, z1, fx, cst1, cst2, Wa, W2, b2, W1 = ctx.saved_tensors
+        dev = x2.device
+        R, cin = x2.shape
+        mid, G = W1.shape[0], W2.shape[0]
+        f32 = dict(dtype=torch.float32, device=dev)
+        du2 = du.reshape(R, -1).contiguous()
+        dfx2 = dfx.reshape(R, -1).contiguous() if dfx is not None else None
+        dx = torch.empty(R, cin, **f32)
+        dW1, dW2, dWa = torch.empty_like(W1), torch.empty_like(W2), torch.empty_like(Wa)
+        db1, dg1, dbe1 = torch.empty(mid, **f32), torch.empty(mid, **f32), torch.empty(mid, **f32)
+        db2, dg2, dbe2 = torch.empty(G, **f32), torch.empty(G, **f32), torch.empty(G, **f32)
+        nbytes = _ph_ws(R, cin, mid, G)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        with _guard(dev):
+            _call(_ph_bwd, _ptr(dfx2), _ptr(du2), _ptr(x2), _ptr(z1), _ptr(fx), R, cin, mid, G, _ptr(W1), _ptr(W2), _ptr(b2), _ptr(Wa),
+                  _ptr(cst1), _ptr(cst2), _ptr(dx), _ptr(dW1), _ptr(db1), _ptr(dg1), _ptr(dbe1), _ptr(dW2), _ptr(db2), _ptr(dg2),
+                  _ptr(dbe2), _ptr(dWa), ws.data_ptr(), nbytes, _tickets(dev).data_ptr(), _stream(dev))
+        return (None, dx.view(ctx.shape), dWa, dW2, db2, dg2, dbe2, dW1, db1, dg1, dbe1)
+
+
+_pt_ok = _sig('pcf_hip_point_tail_supported', [_I, _I, _I])
+_pt_ws = getattr(_lib, 'pcf_hip_point_tail_workspace_bytes')
+_pt_ws.argtypes = [_LL, _I, _I, _I]
+_pt_ws.restype = _Z
+_pt_fwd = _sig('pcf_hip_point_tail_forward', [_P, _LL, _I, _I, _I, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _F, _F,
+                                              _P, _P, _P, _P, _P, _Z, _P, _P])
+_pt_bwd = _sig('pcf_hip_point_tail_backward', [_P, _P, _P, _P, _LL, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                               _P, _Z, _P, _P])
+
+
+def point_tail_chain_supported(c_agg, c_half, c_out):
+    return bool(_pt_ok(int(c_agg), int(c_half), int(c_out)))
+
+
+class _PointTailChain(torch.autograd.Function):
+    """_PointTail through the row chain (csrc/point_chain.hip): three launches forward, six backward (dW3, the wide weight
+    gradient, stays with the contraction kernel of fused_linear.hip)."""
+
+    @staticmethod
+    def forward(ctx, bns, agg, shortcut, W3, b3, g3, be3, W4, b4, g4, be4):
+        dev = agg.device
+        shape = agg.shape
+        a2 = agg.reshape(-1, shape[-1])
+        R, ca = a2.shape
+        ch, co = W3.shape[0], W4.shape[0]
+        bn3, bn4 = bns
+        sc2 = shortcut.reshape(R, -1)
+        f32 = dict(dtype=torch.float32, device=dev)
+        z3, z4, out = torch.empty(R, ch, **f32), torch.empty(R, co, **f32), torch.empty(R, co, **f32)
+        cst3, cst4 = torch.empty(6, ch, **f32), torch.empty(6, co, **f32)
+        nbytes = _pt_ws(R, ca, ch, co)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        m3, m4 = bn_momentum(bn3), bn_momentum(bn4)
+        stream = _stream(dev)
+        with _guard(dev):
+            _call(_pt_fwd, _ptr(a2), R, ca, ch, co, _ptr(W3), _ptr(b3), _ptr(g3), _ptr(be3), _ptr(bn3.running_mean),
+                  _ptr(bn3.running_var), float(m3), _ptr(W4), _ptr(b4), _ptr(g4), _ptr(be4), _ptr(bn4.running_mean),
+                  _ptr(bn4.running_var), float(m4), float(bn3.eps), _ptr(z3), _ptr(z4), _ptr(cst3), _ptr(cst4), ws.data_ptr(),
+                  nbytes, _tickets(dev).data_ptr(), stream)
+            _call(_bnact_fwd, _ptr(z4), _ptr(sc2), R, co, cst4[2].data_ptr(), cst4[3].data_ptr(), _ptr(g4), _ptr(be4),
+                  ACT_LEAKY, _ptr(out), stream)
+        count_batch(bn3)
+        count_batch(bn4)
+        ctx.save_for_backward(a2, sc2, z3, cst3, z4, cst4, W3, W4)
+        ctx.shape = shape
+        return out.view(*shape[:-1], co)
+
+    @staticmethod
+    def backward(ctx, dout):
+        a2, sc2, z3, cst3, z4, cst4, W3, W4 = ctx.saved_tensors
+        dev = a2.device
+        stream = _stream(dev)
+        R, ca = a2.shape
+        ch, co = W3.shape[0], W4.shape[0]
+        d2 = dout.reshape(R, -1).contiguous()
+        f32 = dict(dtype=torch.float32, device=dev)
+        dg4, dbe4, db4 = torch.empty(co, **f32), torch.empty(co, **f32), torch.empty(co, **f32)
+        dg3, dbe3, db3 = torch.empty(ch, **f32), torch.empty(ch, **f32), torch.empty(ch, **f32)
+        g4, g3 = torch.empty(R, co, **f32), torch.empty(R, ch, **f32)
+        dagg, dW4 = torch.empty(R, ca, **f32), torch.empty_like(W4)
+        nbytes = _pt_ws(R, ca, ch, co)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        with _guard(dev):
+            _call(_pt_bwd, _ptr(d2), _ptr(sc2), _ptr(z3), _ptr(z4), R, ca, ch, co, _ptr(W3), _ptr(W4), _ptr(cst3), _ptr(cst4),
+                  _ptr(g4), _ptr(g3), _ptr(dagg), _ptr(dW4), _ptr(db3), _ptr(dg3), _ptr(dbe3), _ptr(db4), _ptr(dg4), _ptr(dbe4),
+                  ws.data_ptr(), nbytes, _tickets(dev).data_ptr(), stream)
+            wg = _WeightGrads(dev, stream)
+            dW3 = wg.add(g3, z3, cst3, ACT_RELU, a2, None, 0)      # g3 is masked already; the ReLU mask is idempotent
+            wg.finish()
+        dsc = g4.view(*ctx.shape[:-1], co) if ctx.needs_input_grad[2] else None
+        return (None, dagg.view(ctx.shape), dsc, dW3, db3, dg3, dbe3, dW4, db4, dg4, dbe4)

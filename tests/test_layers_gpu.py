@@ -710,7 +710,7 @@ def test_fused_edge_chain_full_size(device):
     for k, v in res['fused'].items():
         ref = res['layerwise_bwd'][k]
         scale = float(ref.abs().max()) + 1e-12
-        torch.testing.assert_close(v, ref, rtol=1e-3, atol=1e-3 * scale + 1e-5 * top, msg=lambda m, n=k: f'{n}: {m}')
+        torch.testing.assert_close(v, ref, rtol=1e-3, atol=1e-3 * scale + 2e-5 * top, msg=lambda m, n=k: f'{n}: {m}')
 
 
 def test_fused_edge_chain_inference(device):

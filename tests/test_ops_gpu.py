@@ -652,3 +652,97 @@ def test_fused_linear_rejects_bad_arguments(device):
     # zero rows: nothing to do, no launch
     z, cst = PF._flin_forward(torch.empty(0, 8, device=dev), None, 0, None, W, None, None, 0.0, PF._stream(dev), dev)
     assert z.shape == (0, 4)
+
+
+# ---- PCFLayer head / tail as row chains (csrc/point_chain.hip) against float64 torch autograd --------------------------
+def _bn64(z, g, b, eps=1e-5):
+    return (z - z.mean(0)) * torch.rsqrt(z.var(0, unbiased=False) + eps) * g + b
+
+
+def _close(got, ref, what, tol=1e-3):
+    ref = ref.float()
+    torch.testing.assert_close(got.cpu(), ref, rtol=tol, atol=tol * max(1.0, float(ref.abs().max())), msg=lambda m: f'{what}: {m}')
+
+
+@pytest.mark.parametrize('R', [17, 4099, 80000])
+def test_point_head_row_chain_against_torch(device, R):
+    """unary1 -> guidance_unary -> gathered half of the first guidance layer (layers.py:335, 369, 372) in the three-pass row chain:
+    fx, u, running statistics, dx and all ten parameter gradients against float64 autograd, 1e-3 of the scale."""
+    import pcf_fused as PF
+    import torch.nn.functional as F
+    cin, mid, G = 64, 16, 32
+    assert PF.point_head_chain_supported(cin, mid, G)
+    g = torch.Generator().manual_seed(R)
+    r = lambda *s: torch.randn(*s, generator=g)
+    x, W1, b1, W2, b2, Wa = r(R, cin), r(mid, cin) / cin ** 0.5, r(mid) * 0.1, r(G, mid) / mid ** 0.5, r(G) * 0.1, r(8, G) / G ** 0.5
+    g1, be1, g2, be2 = torch.rand(mid, generator=g) + 0.5, r(mid) * 0.2, torch.rand(G, generator=g) + 0.5, r(G) * 0.2
+    upf, upu = r(R, mid), r(R, 8)
+    bn1, bn2 = torch.nn.BatchNorm1d(mid).to(device), torch.nn.BatchNorm1d(G).to(device)
+    P = [t.to(device).requires_grad_(True) for t in (x, Wa, W2, b2, g2, be2, W1, b1, g1, be1)]
+    fx, u = PF._PointHeadChain.apply((bn1, bn2), *P)
+    torch.autograd.backward([fx, u], [upf.to(device), upu.to(device)])
+    t = lambda v: v.double().requires_grad_(True)
+    Q = [t(v) for v in (x, Wa, W2, b2, g2, be2, W1, b1, g1, be1)]
+    X, A, A2, B2, G2, E2, A1, B1, G1, E1 = Q
+    z1 = X @ A1.t() + B1
+    rfx = F.leaky_relu(_bn64(z1, G1, E1), 0.1)
+    z2 = rfx @ A2.t() + B2
+    ru = _bn64(z2, G2, E2) @ A.t()
+    torch.autograd.backward([rfx, ru], [upf.double(), upu.double()])
+    _close(fx, rfx.detach(), 'fx'); _close(u, ru.detach(), 'u')
+    _close(bn1.running_mean, 0.1 * z1.detach().mean(0), 'running_mean 1')
+    _close(bn2.running_var, 0.9 + 0.1 * z2.detach().var(0, unbiased=True), 'running_var 2')
+    names = ['dx', 'dWa', 'dW2', 'db2', 'dgamma2', 'dbeta2', 'dW1', 'db1', 'dgamma1', 'dbeta1']
+    for n, a, b in zip(names, P, Q):
+        _close(a.grad, b.grad, n)
+    assert float(PF._tickets(device).abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize('R', [17, 4099, 80000])
+def test_point_tail_row_chain_against_torch(device, R):
+    """linear -> unary2 -> + shortcut -> LeakyReLU (layers.py:393-414) in the row chain: output, running statistics, the gradients
+    of the aggregate, of the shortcut and of all eight parameters against float64 autograd, 1e-3 of the scale; and the chain
+    agrees with the layer-by-layer contraction kernels it replaces."""
+    import pcf_fused as PF
+    import torch.nn.functional as F
+    ca, ch, co = 256, 32, 64
+    assert PF.point_tail_chain_supported(ca, ch, co)
+    g = torch.Generator().manual_seed(R + 1)
+    r = lambda *s: torch.randn(*s, generator=g)
+    agg, sc, W3, b3, W4, b4 = r(R, ca), r(R, co), r(ch, ca) / ca ** 0.5, r(ch) * 0.1, r(co, ch) / ch ** 0.5, r(co) * 0.1
+    g3, be3, g4, be4 = torch.rand(ch, generator=g) + 0.5, r(ch) * 0.2, torch.rand(co, generator=g) + 0.5, r(co) * 0.2
+    up = r(R, co)
+    vals = (agg, sc, W3, b3, g3, be3, W4, b4, g4, be4)
+    results = {}
+    for fn in (PF._PointTailChain, PF._PointTail):
+        bn3, bn4 = torch.nn.BatchNorm1d(ch).to(device), torch.nn.BatchNorm1d(co).to(device)
+        with torch.no_grad():
+            bn3.weight.copy_(g3); bn3.bias.copy_(be3); bn4.weight.copy_(g4); bn4.bias.copy_(be4)
+        P = [t.to(device).requires_grad_(True) for t in vals]
+        P[4], P[5], P[8], P[9] = bn3.weight, bn3.bias, bn4.weight, bn4.bias      # the layer-by-layer form reads the modules
+        out = fn.apply((bn3, bn4), *P)
+        out.backward(up.to(device))
+        results[fn] = (out, P, bn3, bn4)
+    out, P, bn3, bn4 = results[PF._PointTailChain]
+    t = lambda v: v.double().requires_grad_(True)
+    Q = [t(v) for v in vals]
+    X, S, A3, B3, G3, E3, A4, B4, G4, E4 = Q
+    z3 = X @ A3.t() + B3
+    z4 = F.relu(_bn64(z3, G3, E3)) @ A4.t() + B4
+    want = F.leaky_relu(_bn64(z4, G4, E4) + S, 0.1)
+    want.backward(up.double())
+    _close(out.detach(), want.detach(), 'out')
+    _close(bn3.running_mean, 0.1 * z3.detach().mean(0), 'running_mean 3')
+    _close(bn4.running_var, 0.9 + 0.1 * z4.detach().var(0, unbiased=True), 'running_var 4')
+    names = ['dagg', 'dshortcut', 'dW3', 'db3', 'dgamma3', 'dbeta3', 'dW4', 'db4', 'dgamma4', 'dbeta4']
+    for n, a, b in zip(names, P, Q):
+        _close(a.grad, b.grad, n)
+    out2, P2, _, _ = results[PF._PointTail]
+    _close(out, out2.detach().cpu(), 'chain vs layer-by-layer', tol=1e-4)
+    for n, a, b in zip(names, P, P2):
+        if n == 'dagg':          # a ReLU whose argument rounds to opposite sides of zero in the two forms changes a whole row
+            bad = ((a.grad - b.grad).abs() > 2e-4 * max(1.0, float(b.grad.abs().max()))).any(dim=1)
+            assert int(bad.sum()) <= max(2, R // 20000), f'{int(bad.sum())} rows of dagg differ between the two forms'
+            continue
+        _close(a.grad, b.grad.cpu(), n + ' (chain vs layer-by-layer)', tol=2e-4 if R < 80000 else 5e-3)   # the same flipped rows
+    assert float(PF._tickets(device).abs().sum()) == 0.0
