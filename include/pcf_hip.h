@@ -139,6 +139,21 @@ int pcf_hip_point_tail_backward(const float* dout, const float* res, const float
                                 float* g3_out, float* dagg, float* dW4, float* db3, float* dgamma3, float* dbeta3, float* db4,
                                 float* dgamma4, float* dbeta4, void* workspace, size_t workspace_bytes, int* tickets, void* stream);
 
+/* pe_convs of PointConvStridePE / PointConvTransposePE (layers.py:599-604, 941-946): WeightNet(3, c_out, [hidden]) = two
+ * Linear+BN+ReLU layers on the edge offsets rel [E,3], training mode (batch statistics), as three-pass row chains that keep
+ * nothing but the input and the output.  Backward: the eight parameter gradients (the offsets carry none). */
+int pcf_hip_pe_chain_supported(int hidden, int c_out);
+size_t pcf_hip_pe_chain_workspace_bytes(long long E, int hidden, int c_out);
+int pcf_hip_pe_chain_forward(const float* rel, long long E, int hidden, int c_out, const float* W1, const float* b1,
+                             const float* gamma1, const float* beta1, float* rmean1, float* rvar1, float mom1, const float* W2,
+                             const float* b2, const float* gamma2, const float* beta2, float* rmean2, float* rvar2, float mom2,
+                             float eps, float* out, float* cst1, float* cst2, void* workspace, size_t workspace_bytes, int* tickets,
+                             void* stream);
+int pcf_hip_pe_chain_backward(const float* dout, const float* rel, long long E, int hidden, int c_out, const float* W1, const float* b1,
+                              const float* W2, const float* b2, float* cst1, float* cst2, float* dW1, float* db1, float* dgamma1,
+                              float* dbeta1, float* dW2, float* db2, float* dgamma2, float* dbeta2, void* workspace,
+                              size_t workspace_bytes, int* tickets, void* stream);
+
 /* ---- attention arithmetic of the ablation layers ------------------------------------------------
  * softmax_aggregate: PointTransformerLayer.forward, layers.py:519-527.  v [R,K,C], logit [R,K,J] (J divides C: the
  *   share_planes groups) -> sm = softmax over K of logit (saved for the backward), out[r,c] = sum_k v[r,k,c] * sm[r,k,c % J].

@@ -468,7 +468,6 @@ __global__ __launch_bounds__(BLOCK) void flin_bwd_w_kernel(const BwdWArgs g) {
     using TB = Tile<BN, false, BW_KS>;
     __shared__ __align__(16) float sA[BW_KS * TA::STRIDE];
     __shared__ __align__(16) float sB[BW_KS * TB::STRIDE];
-    __shared__ int s_last;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int wave = wave_id(), lane = lane_id(), wm = wave / WN, wn = wave % WN;
     const long long rbeg = (long long)blockIdx.z * g.r_per_split;

@@ -30,9 +30,11 @@ namespace pcf {
 constexpr int PT = 20;                   // row stride of the 16 x 16 transposition tiles
 constexpr int PC_MAXB = 256;             // workgroups per pass: a wave per SIMD, tile loads hidden by the hand pipelining below
 constexpr int PC_GROUP = 16;             // partial lists per first-level group of pass_totals
-// floats of the statistics area of a pass whose widest layer has maxc channels: the workgroups' lists + the groups' doubles
-static inline size_t pc_part_floats(int maxc) { return (size_t)PC_MAXB * 2 * maxc + (size_t)(PC_MAXB / PC_GROUP) * 2 * maxc * 2; }
 constexpr int PC_CH = 8;                 // width of u (hidden width of the guidance MLP)
+constexpr int PE_MAXB = 2048;            // the edge-row chains (millions of rows, 34-140 registers): up to eight waves per SIMD
+// floats of the statistics area of a pass of at most nb workgroups whose widest layer has maxc channels: the workgroups'
+// lists + the groups' doubles
+static inline size_t pc_part_floats(int maxc, int nb = PC_MAXB) { return (size_t)nb * 2 * maxc + (size_t)(nb / PC_GROUP + 1) * 2 * maxc * 2; }
 
 __device__ __forceinline__ f32x4 v4(float4 v) { return f32x4{v.x, v.y, v.z, v.w}; }
 __device__ __forceinline__ float4 f4(f32x4 v) { return make_float4(v[0], v[1], v[2], v[3]); }
@@ -95,7 +97,7 @@ __device__ __forceinline__ bool pass_totals(const f32x4 (&s1)[NT], const f32x4 (
     __shared__ float wsum[NWAVE][NV];
     __shared__ double red[BLOCK];
     __shared__ int s_last;
-    double* gpart = reinterpret_cast<double*>(part + (size_t)PC_MAXB * NV);
+    double* gpart = reinterpret_cast<double*>(part + (size_t)gridDim.x * NV);
     const int lane = lane_id(), wave = wave_id(), p = lane & 15, g = lane >> 4;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(BLOCK) void head_fwd_kernel(const HeadArgs a) {
     __shared__ double tot[2 * 16 * (NM > NG ? NM : NG)];
     const int lane = lane_id(), p = lane & 15, g = lane >> 4;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    constexpr int CI = 16 * KI, CM = 16 * NM, CG = 16 * NG;
+    constexpr int CM = 16 * NM, CG = 16 * NG;
     constexpr int NIN = PASS == 1 ? KI : NM;                 // 16-channel tiles of the row a pass reads: x | z1 | fx
     const float* in = PASS == 1 ? a.x : PASS == 2 ? a.z1 : a.fx;
     const long long ntiles = (a.R + 15) / 16, stride = (long long)gridDim.x * NWAVE;
@@ -727,6 +729,182 @@ __global__ __launch_bounds__(BLOCK) void tail_bwd_kernel(const TailArgs a) {
     }
 }
 
+// ---- positional-encoding MLP of the strided / transposed PointConvs ------------------------------------------------------
+// pe_convs = WeightNet(3, L, hidden_unit=[H]) (layers.py:599-604, 941-946): two Linear+BN+ReLU layers 3 -> H -> L on every
+// edge, rows = edges.  The three offsets are ONE contraction step of the 16x16x4 product (k = 0..2, the fourth zero), so a
+// lane loads one float per tile and layer 1 is one MFMA per 16 hidden channels; nothing but the input offsets and the
+// output is kept: every pass recomputes the chain in front of it.
+//   forward   F1: statistics of z1           F2: statistics of z2 = W2 ReLU(BN1(z1))         F3: out = ReLU(BN2(z2)) stored
+//   backward  B1: g2 = dout * ReLU'(.), sums of layer 2     B2: dz2, dW2 tiles, g1 = (W2^T dz2) * ReLU'(.), sums of layer 1
+//             B3: dz1, dW1 tiles                                                  (the offsets carry no gradient)
+struct PeArgs {
+    const float* rel; float* out;                                // [E,3] in; [E,16NL]
+    const float* W1; const float* b1; const float* W2; const float* b2;     // [H,3], [H], [L,H], [L]
+    float* cst1; float* cst2;
+    const float* gamma1; const float* beta1; float* rmean1; float* rvar1;
+    const float* gamma2; const float* beta2; float* rmean2; float* rvar2;
+    float eps, mom1, mom2;
+    const float* dout;                                           // backward: [E,16NL]
+    float* dgamma1; float* dbeta1; float* db1; float* dgamma2; float* dbeta2; float* db2;
+    float* part; int* ticket; float* pdw1; float* pdw2;
+    long long R;
+};
+
+// FWD: PASS 1..3 as above; !FWD: PASS 1..3 = B1..B3
+template <int NH, int NL, int PASS, bool FWD>
+__global__ __launch_bounds__(BLOCK) void pe_chain_kernel(const PeArgs a) {
+    constexpr int CH = 16 * NH, CL = 16 * NL;
+    constexpr bool L2 = !(FWD && PASS == 1);                   // layer 2 is evaluated
+    constexpr bool TR = !FWD && PASS >= 2;                     // W2^T is needed
+    constexpr int NDW = FWD ? 1 : PASS == 2 ? NL * NH : PASS == 3 ? NH : 1;
+    constexpr int NTB = FWD ? 1 : PASS == 2 ? NL + NH : PASS == 3 ? NH : 1;
+    constexpr int NS = FWD ? (PASS == 1 ? NH : NL) : (PASS == 1 ? NL : NH);
+    __shared__ float4 wl[(L2 ? NL * NH : 1) * WAVE];
+    __shared__ float4 wt[(TR ? NH * NL : 1) * WAVE];
+    __shared__ __align__(16) float tbuf[NWAVE * NTB * 16 * PT];
+    __shared__ float red[NDW * 256];
+    __shared__ double tot[2 * 16 * (NH > NL ? NH : NL)];
+    const int lane = lane_id(), wave = wave_id(), p = lane & 15, g = lane >> 4;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const long long ntiles = (a.R + 15) / 16, stride = (long long)gridDim.x * NWAVE;
+    long long t = (long long)blockIdx.x * NWAVE + wave_id();
+    constexpr int ND = FWD ? 1 : NL;
+    auto load_x = [&](long long tt) { const long long row = tt * 16 + p; return (g < 3 && row < a.R) ? a.rel[row * 3 + g] : 0.f; };
+    auto load_d = [&](long long tt, f32x4 (&d)[ND]) {
+        if (!FWD) {
+#pragma unroll
+            for (int nl = 0; nl < NL; ++nl) d[nl] = ld_row4(a.dout, tt * 16 + p, a.R, CL, 16 * nl + 4 * g);
+        }
+    };
+    float xn = 0.f;
+    f32x4 dn[ND];
+    if (t < ntiles) { xn = load_x(t); load_d(t, dn); }
+    if (L2) stage_matrix(wl, a.W2, CL, CH, false);
+    if (TR) stage_matrix(wt, a.W2, CL, CH, true);
+    float* tb = tbuf + wave * NTB * 16 * PT;
+    float w1[NH];
+    f32x4 bias1[NH], sc1[NH], sh1[NH], d11[NH], d01[NH], bias2[NL], sc2[NL], sh2[NL], d12[NL], d02[NL];
+#pragma unroll
+    for (int nh = 0; nh < NH; ++nh) {
+        const int c0 = 16 * nh + 4 * g;
+        w1[nh] = g < 3 ? a.W1[(16 * nh + p) * 3 + g] : 0.f;
+        bias1[nh] = v4(ld4(a.b1 + c0));
+        if (L2) { sc1[nh] = cst_row4(a.cst1, CH, 0, c0); sh1[nh] = cst_row4(a.cst1, CH, 1, c0); }
+        if (!FWD && PASS == 3) { d11[nh] = cst_row4(a.cst1, CH, 4, c0); d01[nh] = cst_row4(a.cst1, CH, 5, c0); }
+    }
+    if (L2) {
+#pragma unroll
+        for (int nl = 0; nl < NL; ++nl) {
+            const int c0 = 16 * nl + 4 * g;
+            bias2[nl] = v4(ld4(a.b2 + c0));
+            if (!(FWD && PASS == 2)) { sc2[nl] = cst_row4(a.cst2, CL, 0, c0); sh2[nl] = cst_row4(a.cst2, CL, 1, c0); }
+            if (TR) { d12[nl] = cst_row4(a.cst2, CL, 4, c0); d02[nl] = cst_row4(a.cst2, CL, 5, c0); }
+        }
+    }
+    f32x4 s1[NS], s2[NS], dw[NDW];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) { s1[i] = zero4; s2[i] = zero4; }
+#pragma unroll
+    for (int i = 0; i < NDW; ++i) dw[i] = zero4;
+    __syncthreads();
+    for (; t < ntiles; t += stride) {
+        const long long row = t * 16 + p;
+        const float valid = row < a.R ? 1.f : 0.f;
+        const float x = xn;
+        f32x4 dout[ND];
+#pragma unroll
+        for (int i = 0; i < ND; ++i) dout[i] = dn[i];
+        if (t + stride < ntiles) { xn = load_x(t + stride); load_d(t + stride, dn); }
+        f32x4 z1[NH], y1[NH];
+#pragma unroll
+        for (int nh = 0; nh < NH; ++nh) {
+            z1[nh] = PCF_MFMA(w1[nh], x, bias1[nh]);
+            if (FWD && PASS == 1) { s1[nh] += z1[nh] * valid; s2[nh] += z1[nh] * z1[nh] * valid; }
+            else y1[nh] = relu4p(z1[nh] * sc1[nh] + sh1[nh]);
+        }
+        if (FWD && PASS == 1) continue;
+        f32x4 z2[NL];
+#pragma unroll
+        for (int nl = 0; nl < NL; ++nl) {
+            f32x4 z = bias2[nl];
+#pragma unroll
+            for (int nh = 0; nh < NH; ++nh) z = pmm(wl, nl * NH + nh, lane, y1[nh], z);
+            z2[nl] = z;
+            if (FWD && PASS == 2) { s1[nl] += z * valid; s2[nl] += z * z * valid; }
+            if (FWD && PASS == 3) st_row4(a.out, row, a.R, CL, 16 * nl + 4 * g, relu4p(z * sc2[nl] + sh2[nl]));
+        }
+        if (FWD) continue;
+        f32x4 g2[NL];
+#pragma unroll
+        for (int nl = 0; nl < NL; ++nl) {
+            g2[nl] = drelu4(dout[nl], z2[nl] * sc2[nl] + sh2[nl]) * valid;
+            if (PASS == 1) { s1[nl] += g2[nl]; s2[nl] += g2[nl] * z2[nl]; }
+        }
+        if (PASS == 1) continue;
+        f32x4 dz2[NL];
+#pragma unroll
+        for (int nl = 0; nl < NL; ++nl) {
+            dz2[nl] = (g2[nl] * sc2[nl] + (z2[nl] * d12[nl] + d02[nl])) * valid;
+            if (PASS == 2) put_tile(tb + nl * 16 * PT, dz2[nl], p, g);
+        }
+        if (PASS == 2) {
+#pragma unroll
+            for (int nh = 0; nh < NH; ++nh) put_tile(tb + (NL + nh) * 16 * PT, y1[nh] * valid, p, g);
+#pragma unroll
+            for (int nl = 0; nl < NL; ++nl)
+#pragma unroll
+                for (int nh = 0; nh < NH; ++nh) dw[nl * NH + nh] = pouter(tb + nl * 16 * PT, tb + (NL + nh) * 16 * PT, p, g, dw[nl * NH + nh]);
+        }
+        float relT[4];
+        if (PASS == 3) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {                   // offsets of row 4s + g, coordinate p: the tile's 192 bytes again
+                const long long r = t * 16 + 4 * s + g;
+                relT[s] = (p < 3 && r < a.R) ? a.rel[r * 3 + p] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int nh = 0; nh < NH; ++nh) {
+            f32x4 d = zero4;
+#pragma unroll
+            for (int nl = 0; nl < NL; ++nl) d = pmm(wt, nh * NL + nl, lane, dz2[nl], d);
+            const f32x4 g1 = drelu4(d, z1[nh] * sc1[nh] + sh1[nh]) * valid;
+            if (PASS == 2) { s1[nh] += g1; s2[nh] += g1 * z1[nh]; }
+            else {
+                const f32x4 dz1 = (g1 * sc1[nh] + (z1[nh] * d11[nh] + d01[nh])) * valid;
+                put_tile(tb + nh * 16 * PT, dz1, p, g);
+                const float* dzb = tb + nh * 16 * PT;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) dw[nh] = PCF_MFMA(dzb[(4 * s + g) * PT + p], relT[s], dw[nh]);
+            }
+        }
+    }
+    if (!FWD && PASS >= 2) flush_dw<NDW>(dw, red, PASS == 2 ? a.pdw2 : a.pdw1);
+    if (PASS == 3) return;
+    if (!pass_totals<NS>(s1, s2, a.part, a.ticket, tot)) return;
+    constexpr int NC = 16 * NS;
+    if (threadIdx.x < NC) {
+        const double S1 = tot[threadIdx.x], S2 = tot[NC + threadIdx.x];
+        if (FWD && PASS == 1) bn_fwd_constants(a.cst1, NC, threadIdx.x, S1, S2, (double)a.R, a.gamma1, a.beta1, a.rmean1, a.rvar1, a.eps, a.mom1);
+        if (FWD && PASS == 2) bn_fwd_constants(a.cst2, NC, threadIdx.x, S1, S2, (double)a.R, a.gamma2, a.beta2, a.rmean2, a.rvar2, a.eps, a.mom2);
+        if (!FWD && PASS == 1) bn_bwd_constants(a.cst2, NC, threadIdx.x, S1, S2, (double)a.R, a.dgamma2, a.dbeta2, a.db2);
+        if (!FWD && PASS == 2) bn_bwd_constants(a.cst1, NC, threadIdx.x, S1, S2, (double)a.R, a.dgamma1, a.dbeta1, a.db1);
+    }
+}
+
+template <int NH, int NL>
+static void pe_launch_forward(const PeArgs& a, int grid, hipStream_t s) {
+    hipLaunchKernelGGL((pe_chain_kernel<NH, NL, 1, true>), dim3(grid), dim3(BLOCK), 0, s, a);
+    hipLaunchKernelGGL((pe_chain_kernel<NH, NL, 2, true>), dim3(grid), dim3(BLOCK), 0, s, a);
+    hipLaunchKernelGGL((pe_chain_kernel<NH, NL, 3, true>), dim3(grid), dim3(BLOCK), 0, s, a);
+}
+template <int NH, int NL>
+static void pe_launch_backward(const PeArgs& a, int grid, hipStream_t s) {
+    hipLaunchKernelGGL((pe_chain_kernel<NH, NL, 1, false>), dim3(grid), dim3(BLOCK), 0, s, a);
+    hipLaunchKernelGGL((pe_chain_kernel<NH, NL, 2, false>), dim3(grid), dim3(BLOCK), 0, s, a);
+    hipLaunchKernelGGL((pe_chain_kernel<NH, NL, 3, false>), dim3(grid), dim3(BLOCK), 0, s, a);
+}
+
 // Weight-gradient partial tiles -> matrices.  Up to DWR_MAX groups; group i: nblocks lists of `tiles` 16x16 tiles laid out
 // [tile = to * tiles_c + tc][o_local][c_local]; out[o][c] for o < rows, c < cols (row-major, leading dimension cols).
 constexpr int DWR_MAX = 4;
@@ -760,6 +938,11 @@ __global__ __launch_bounds__(1024) void dw_reduce_kernel(const DwReduceArgs f) {
     if (o < f.rows[i] && c < f.cols[i]) f.out[i][(size_t)o * f.cols[i] + c] = t;
 }
 
+// edge rows: at least four tiles per wave, up to PE_MAXB workgroups
+static inline int pe_grid(long long E) {
+    const long long tiles = (E + 15) / 16;
+    return (int)std::max<long long>(1, std::min<long long>((tiles + 4 * NWAVE - 1) / (4 * NWAVE), PE_MAXB));
+}
 static inline int pc_grid(long long R) {
     const long long tiles = (R + 15) / 16;
     return (int)std::max<long long>(1, std::min<long long>((tiles + NWAVE - 1) / NWAVE, PC_MAXB));
@@ -937,6 +1120,87 @@ int pcf_hip_point_tail_backward(const float* dout, const float* res, const float
     r.part[0] = a.pdw4; r.out[0] = dW4; r.tiles_c[0] = c_half / 16; r.tiles[0] = (c_out / 16) * (c_half / 16); r.rows[0] = c_out; r.cols[0] = c_half;
     r.block0[0] = 0; r.block0[1] = r.tiles[0] * 4;
     hipLaunchKernelGGL(dw_reduce_kernel, dim3(r.block0[1]), dim3(1024), 0, s, r);
+    return check_launch("dw_reduce_kernel");
+}
+
+// (hidden width, output width) of the positional-encoding MLPs the chain is instantiated for: out_channel / 4 and
+// min(out_channel / 4, 32) for out_channel = 64, 128, 256 (the 512-wide levels have a few thousand edges: not worth the
+// 128-channel instantiation, whose weight fragments do not fit the register file)
+int pcf_hip_pe_chain_supported(int hidden, int c_out) {
+    return ((hidden == 16 && c_out == 16) || ((hidden == 32 || hidden == 64) && c_out == 32)) ? 1 : 0;
+}
+
+size_t pcf_hip_pe_chain_workspace_bytes(long long E, int hidden, int c_out) {
+    if (E < 0 || !pcf_hip_pe_chain_supported(hidden, c_out)) return 0;
+    const size_t nb = pcf::pe_grid(E);
+    return pcf::pc_part_floats(std::max(hidden, c_out), pcf::PE_MAXB) * 4 + nb * ((size_t)(hidden / 16) * (c_out / 16) + hidden / 16) * 256 * 4 + 1024;
+}
+
+// out [E, c_out] = ReLU(BN2(W2 ReLU(BN1(W1 rel + b1)) + b2)) with batch statistics; cst1 [6][hidden], cst2 [6][c_out] rows
+// 0..3 and the running statistics are written
+int pcf_hip_pe_chain_forward(const float* rel, long long E, int hidden, int c_out, const float* W1, const float* b1,
+                             const float* gamma1, const float* beta1, float* rmean1, float* rvar1, float mom1, const float* W2,
+                             const float* b2, const float* gamma2, const float* beta2, float* rmean2, float* rvar2, float mom2,
+                             float eps, float* out, float* cst1, float* cst2, void* workspace, size_t workspace_bytes, int* tickets,
+                             void* stream) {
+    using namespace pcf;
+    if (!pcf_hip_pe_chain_supported(hidden, c_out))
+        return fail(PCF_E_UNSUPPORTED, "pe_chain: widths (%d, %d) are not instantiated", hidden, c_out);
+    PCF_REQUIRE(E >= 0 && E < (1ll << 31), "pe_chain: bad row count");
+    if (E == 0) return ok();
+    PCF_REQUIRE(rel && W1 && b1 && gamma1 && beta1 && W2 && b2 && gamma2 && beta2 && out && cst1 && cst2 && tickets, "pe_chain_forward: null pointer");
+    PCF_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= pcf_hip_pe_chain_workspace_bytes(E, hidden, c_out),
+                "pe_chain_forward: workspace too small or misaligned");
+    PCF_REQUIRE(aligned16(out) && aligned16(cst1) && aligned16(cst2) && aligned16(b1) && aligned16(b2) && aligned16(W2),
+                "pe_chain_forward: buffers must be 16-byte aligned");
+    PeArgs a{};
+    a.rel = rel; a.out = out; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.cst1 = cst1; a.cst2 = cst2;
+    a.gamma1 = gamma1; a.beta1 = beta1; a.rmean1 = rmean1; a.rvar1 = rvar1; a.gamma2 = gamma2; a.beta2 = beta2; a.rmean2 = rmean2; a.rvar2 = rvar2;
+    a.eps = eps; a.mom1 = mom1; a.mom2 = mom2; a.part = static_cast<float*>(workspace); a.ticket = tickets; a.R = E;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = pe_grid(E);
+    if (hidden == 16) pe_launch_forward<1, 1>(a, grid, s);
+    else if (hidden == 32) pe_launch_forward<2, 2>(a, grid, s);
+    else pe_launch_forward<4, 2>(a, grid, s);
+    return check_launch("pe_chain_kernel<forward>");
+}
+
+// parameter gradients of both layers from dout [E, c_out]; cst1 / cst2 rows 4, 5 are written
+int pcf_hip_pe_chain_backward(const float* dout, const float* rel, long long E, int hidden, int c_out, const float* W1, const float* b1,
+                              const float* W2, const float* b2, float* cst1, float* cst2, float* dW1, float* db1, float* dgamma1,
+                              float* dbeta1, float* dW2, float* db2, float* dgamma2, float* dbeta2, void* workspace,
+                              size_t workspace_bytes, int* tickets, void* stream) {
+    using namespace pcf;
+    if (!pcf_hip_pe_chain_supported(hidden, c_out))
+        return fail(PCF_E_UNSUPPORTED, "pe_chain: widths (%d, %d) are not instantiated", hidden, c_out);
+    PCF_REQUIRE(E >= 1 && E < (1ll << 31), "pe_chain_backward: bad row count");
+    PCF_REQUIRE(dout && rel && W1 && b1 && W2 && b2 && cst1 && cst2 && dW1 && db1 && dgamma1 && dbeta1 && dW2 && db2 && dgamma2 && dbeta2 &&
+                tickets, "pe_chain_backward: null pointer");
+    PCF_REQUIRE(workspace && aligned16(workspace) && workspace_bytes >= pcf_hip_pe_chain_workspace_bytes(E, hidden, c_out),
+                "pe_chain_backward: workspace too small or misaligned");
+    PCF_REQUIRE(aligned16(dout) && aligned16(cst1) && aligned16(cst2) && aligned16(b1) && aligned16(b2) && aligned16(W2),
+                "pe_chain_backward: buffers must be 16-byte aligned");
+    PeArgs a{};
+    a.rel = rel; a.dout = dout; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.cst1 = cst1; a.cst2 = cst2;
+    a.dgamma1 = dgamma1; a.dbeta1 = dbeta1; a.db1 = db1; a.dgamma2 = dgamma2; a.dbeta2 = dbeta2; a.db2 = db2;
+    a.ticket = tickets; a.R = E;
+    float* w = static_cast<float*>(workspace);
+    a.part = w; w += pc_part_floats(std::max(hidden, c_out), PE_MAXB);
+    const int nh = hidden / 16, nl = c_out / 16;
+    const int grid = pe_grid(E);
+    a.pdw2 = w; w += (size_t)grid * nl * nh * 256;
+    a.pdw1 = w;
+    hipStream_t s = (hipStream_t)stream;
+    if (hidden == 16) pe_launch_backward<1, 1>(a, grid, s);
+    else if (hidden == 32) pe_launch_backward<2, 2>(a, grid, s);
+    else pe_launch_backward<4, 2>(a, grid, s);
+    if (int e = check_launch("pe_chain_kernel<backward>")) return e;
+    DwReduceArgs r{};
+    r.n = 2; r.nblocks = grid;
+    r.part[0] = a.pdw2; r.out[0] = dW2; r.tiles_c[0] = nh; r.tiles[0] = nl * nh; r.rows[0] = c_out; r.cols[0] = hidden;
+    r.part[1] = a.pdw1; r.out[1] = dW1; r.tiles_c[1] = 1; r.tiles[1] = nh; r.rows[1] = hidden; r.cols[1] = 3;
+    r.block0[0] = 0; r.block0[1] = r.tiles[0] * 4; r.block0[2] = r.block0[1] + r.tiles[1] * 4;
+    hipLaunchKernelGGL(dw_reduce_kernel, dim3(r.block0[2]), dim3(1024), 0, s, r);
     return check_launch("dw_reduce_kernel");
 }
 

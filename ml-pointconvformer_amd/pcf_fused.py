@@ -1366,3 +1366,75 @@ class _PointTailChain(torch.autograd.Function):
             wg.finish()
         dsc = g4.view(*ctx.shape[:-1], co) if ctx.needs_input_grad[2] else None
         return (None, dagg.view(ctx.shape), dsc, dW3, db3, dg3, dbe3, dW4, db4, dg4, dbe4)
+
+
+# --------------------------------------------------------------------------------------------------
+# pe_convs of the strided / transposed PointConvs as a row chain over the edges (csrc/point_chain.hip)
+# --------------------------------------------------------------------------------------------------
+_pe_ok = _sig('pcf_hip_pe_chain_supported', [_I, _I])
+_pe_ws = getattr(_lib, 'pcf_hip_pe_chain_workspace_bytes')
+_pe_ws.argtypes = [_LL, _I, _I]
+_pe_ws.restype = _Z
+_pe_fwd = _sig('pcf_hip_pe_chain_forward', [_P, _LL, _I, _I, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P,
+                                            _P, _Z, _P, _P])
+_pe_bwd = _sig('pcf_hip_pe_chain_backward', [_P, _P, _LL, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P, _P])
+
+
+def pe_chain_supported(cin, hidden, cout):
+    """Two Linear_BN + ReLU layers 3 -> hidden -> cout at the widths the chain is instantiated for."""
+    return cin == 3 and len(hidden) == 1 and bool(_pe_ok(int(hidden[0]), int(cout)))
+
+
+class _PEChain(torch.autograd.Function):
+    """feat_pe = ReLU(BN2(W2 ReLU(BN1(W1 rel + b1)) + b2)), training mode: three launches forward, four backward; only the
+    offsets and the output exist in HBM."""
+
+    @staticmethod
+    def forward(ctx, bns, rel, W1, b1, g1, be1, W2, b2, g2, be2):
+        dev = rel.device
+        shape = rel.shape
+        r2 = rel.reshape(-1, 3)
+        E = r2.shape[0]
+        H, L = W1.shape[0], W2.shape[0]
+        bn1, bn2 = bns
+        f32 = dict(dtype=torch.float32, device=dev)
+        out = torch.empty(E, L, **f32)
+        cst1, cst2 = torch.empty(6, H, **f32), torch.empty(6, L, **f32)
+        nbytes = _pe_ws(E, H, L)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        m1, m2 = bn_momentum(bn1), bn_momentum(bn2)
+        with _guard(dev):
+            _call(_pe_fwd, _ptr(r2), E, H, L, _ptr(W1), _ptr(b1), _ptr(g1), _ptr(be1), _ptr(bn1.running_mean), _ptr(bn1.running_var),
+                  float(m1), _ptr(W2), _ptr(b2), _ptr(g2), _ptr(be2), _ptr(bn2.running_mean), _ptr(bn2.running_var), float(m2),
+                  float(bn1.eps), _ptr(out), _ptr(cst1), _ptr(cst2), ws.data_ptr(), nbytes, _tickets(dev).data_ptr(), _stream(dev))
+        count_batch(bn1)
+        count_batch(bn2)
+        ctx.save_for_backward(r2, cst1, cst2, W1, b1, W2, b2)
+        return out.view(*shape[:-1], L)
+
+    @staticmethod
+    def backward(ctx, dout):
+        r2, cst1, cst2, W1, b1, W2, b2 = ctx.saved_tensors
+        dev = r2.device
+        E = r2.shape[0]
+        H, L = W1.shape[0], W2.shape[0]
+        f32 = dict(dtype=torch.float32, device=dev)
+        d2 = dout.reshape(E, L).contiguous()
+        dW1, dW2 = torch.empty_like(W1), torch.empty_like(W2)
+        db1, dg1, dbe1 = torch.empty(H, **f32), torch.empty(H, **f32), torch.empty(H, **f32)
+        db2, dg2, dbe2 = torch.empty(L, **f32), torch.empty(L, **f32), torch.empty(L, **f32)
+        nbytes = _pe_ws(E, H, L)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        with _guard(dev):
+            _call(_pe_bwd, _ptr(d2), _ptr(r2), E, H, L, _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2), _ptr(cst1), _ptr(cst2), _ptr(dW1),
+                  _ptr(db1), _ptr(dg1), _ptr(dbe1), _ptr(dW2), _ptr(db2), _ptr(dg2), _ptr(dbe2), ws.data_ptr(), nbytes,
+                  _tickets(dev).data_ptr(), _stream(dev))
+        return (None, None, dW1, db1, dg1, dbe1, dW2, db2, dg2, dbe2)
+
+
+def pe_chain(rel, layers):
+    """layers: two (nn.Linear, nn.BatchNorm1d) pairs in training mode; the offsets carry no gradient."""
+    _floats(rel=rel)
+    (l1, bn1), (l2, bn2) = layers
+    return _PEChain.apply((bn1, bn2), rel.contiguous(), l1.weight.contiguous(), l1.bias, bn1.weight, bn1.bias, l2.weight.contiguous(),
+                          l2.bias, bn2.weight, bn2.bias)

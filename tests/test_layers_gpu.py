@@ -676,6 +676,69 @@ def test_weightnet_chain_against_layer_at_a_time(device, rows, cin, cout, traini
         torch.testing.assert_close(b.float(), c.float(), rtol=1e-4, atol=1e-5, msg=lambda m, k=n: f'{k}: {m}')
 
 
+@pytest.mark.parametrize('rows,hidden,cout', [((1, 333, 16), 16, 16), ((2, 500, 16), 32, 32), ((1, 77, 3), 64, 32),
+                                              ((1, 80000, 16), 32, 32), ((1, 1000, 16), 128, 32)])
+def test_pe_chain_against_float64_and_layer_at_a_time(device, rows, hidden, cout):
+    """pe_convs = WeightNet(3, cout, [hidden]) (layers.py:599-604, 941-946) through the row chain over the edges (three
+    passes forward, three backward, nothing but the output stored): output, running statistics and the eight parameter
+    gradients against float64 autograd at 1e-3 of the scale, and against the same module run layer by layer.  hidden = 128
+    (the 512-wide levels) is not instantiated and must take the layer-by-layer path."""
+    import copy
+    import pcf_layers
+    import pcf_fused
+    import torch.nn.functional as F
+    torch.manual_seed(rows[1] + hidden)
+    wn = pcf_layers.WeightNet(3, cout, hidden_unit=[hidden], efficient=True).to(device)
+    with torch.no_grad():
+        for m in wn.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.3, 0.3)
+    ref = copy.deepcopy(wn)
+    ref.no_chain = True
+    wn.train()
+    ref.train()
+    assert pcf_fused.pe_chain_supported(3, (hidden,), cout) == (hidden != 128)
+    rel = torch.randn(*rows, 3, device=device) * 0.3
+    up = torch.randn(*rows, cout, device=device)
+    pcf_cuda = __import__('pcf_cuda')
+    pcf_cuda.launch_log(True)
+    out = wn(rel)
+    out.backward(up)
+    names = pcf_cuda.read_launch_log()
+    pcf_cuda.launch_log(False)
+    assert any('pe_chain' in n for n in names) == (hidden != 128), names
+    want = ref(rel)
+    want.backward(up)
+    # float64 reference
+    P = {n: p.detach().double().cpu().requires_grad_(True) for n, p in ref.named_parameters()}
+    x = rel.double().cpu().reshape(-1, 3)
+
+    def bn(z, g, b):
+        return (z - z.mean(0)) * torch.rsqrt(z.var(0, unbiased=False) + 1e-5) * g + b
+
+    z1 = x @ P['mlp_convs.0.c.weight'].t() + P['mlp_convs.0.c.bias']
+    y1 = F.relu(bn(z1, P['mlp_convs.0.bn.weight'], P['mlp_convs.0.bn.bias']))
+    z2 = y1 @ P['mlp_convs.1.c.weight'].t() + P['mlp_convs.1.c.bias']
+    o64 = F.relu(bn(z2, P['mlp_convs.1.bn.weight'], P['mlp_convs.1.bn.bias']))
+    o64.backward(up.double().cpu().reshape(-1, cout))
+
+    def close(got, ref_, what, tol):
+        ref_ = ref_.float()
+        torch.testing.assert_close(got.detach().cpu().reshape(ref_.shape), ref_, rtol=tol, atol=tol * max(1.0, float(ref_.abs().max())),
+                                   msg=lambda m: f'{what}: {m}')
+
+    close(out, o64.detach().reshape(out.shape), 'out vs float64', 1e-3)
+    for n, p in wn.named_parameters():
+        close(p.grad, P[n].grad, n + ' vs float64', 2e-3)
+    close(wn.mlp_convs[0].bn.running_mean, 0.1 * z1.detach().mean(0), 'running_mean 1', 1e-3)
+    close(wn.mlp_convs[1].bn.running_var, 0.9 + 0.1 * z2.detach().var(0, unbiased=True), 'running_var 2', 1e-3)
+    close(out, want.detach().cpu(), 'out vs layer by layer', 1e-4)
+    for (n, b), (_, c) in zip(wn.named_buffers(), ref.named_buffers()):
+        close(b.float(), c.float().cpu(), n, 1e-4)
+    assert float(pcf_fused._tickets(device).abs().sum()) == 0.0
+
+
 def test_fused_edge_chain_full_size(device):
     """BASELINE's full size (one packed cloud of 80 000 points, K = 16, 1.28 M edges): the fused three-pass backward
     (weight gradients of the first layers from moments accumulated over all edges) against the layer-at-a-time
