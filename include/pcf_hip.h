@@ -154,6 +154,17 @@ int pcf_hip_pe_chain_backward(const float* dout, const float* rel, long long E, 
                               float* dbeta1, float* dW2, float* db2, float* dgamma2, float* dbeta2, void* workspace,
                               size_t workspace_bytes, int* tickets, void* stream);
 
+/* clip_grad_norm_ + AdamW.step() of the training loop (train_ScanNet_DDP_WarmUP.py:237-241, :421) over lists of parameter
+ * tensors carried as kernel arguments (at most pcf_hip_adamw_max_tensors() per call; one partial per pcf_hip_adamw_chunk()
+ * elements).  rec: device float[8] = lr, step, norm, coef, 1 - beta1^step, sqrt(1 - beta2^step).  Sequence per step: phase 0
+ * per list, pcf_hip_adamw_finish, phase 1 per list.  Arithmetic of torch.optim.AdamW(fused=True). */
+int pcf_hip_adamw_max_tensors(void);
+int pcf_hip_adamw_chunk(void);
+int pcf_hip_adamw_list(int phase, int n, float* const* params, float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                       const long long* counts, float* rec, float* partials, int partial0, double beta1, double beta2, double eps,
+                       double weight_decay, void* stream);
+int pcf_hip_adamw_finish(const float* partials, int n_partials, float* rec, float max_norm, double beta1, double beta2, void* stream);
+
 /* ---- attention arithmetic of the ablation layers ------------------------------------------------
  * softmax_aggregate: PointTransformerLayer.forward, layers.py:519-527.  v [R,K,C], logit [R,K,J] (J divides C: the
  *   share_planes groups) -> sm = softmax over K of logit (saved for the backward), out[r,c] = sum_k v[r,k,c] * sm[r,k,c % J].

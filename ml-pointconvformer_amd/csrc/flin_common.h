@@ -21,12 +21,37 @@ __device__ __forceinline__ float fl_dact(int act, float u) {
 // Hand-over between workgroups of ONE launch (per-workgroup partial sums -> the workgroup that finishes last).  The L2s
 // of the eight XCDs are not coherent with each other for ordinary accesses, so an agent-scope release (__threadfence)
 // writes back every dirty L2 line of the XCD -- with the megabytes of output a kernel has just stored that costs more
-// than the kernel (measured: 21 -> 75 us for an [80k, 256] x [256, 32] product).  Instead the few hundred floats that
-// cross workgroups are written and read with agent-scope atomic accesses (which bypass the non-coherent path), and a
-// workgroup-scope release (s_waitcnt only) orders them before the ticket.
-__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void publish() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+// than the kernel (measured: 21 -> 75 us for an [80k, 256] x [256, 32] product).  Instead the few hundred values that
+// cross workgroups are written and read with agent-scope read-modify-write atomics (exchange / add 0), which are performed
+// at the point all XCDs share, and the writer WAITS for the old value to come back before it takes its ticket:
+//   * a workgroup-scope release fence compiles to no vector-memory wait at all on this target (the waves of a workgroup share
+//     one L1), so "atomic store; fence(workgroup); ticket" let the ticket overtake the store now and then -- with 2048 short
+//     workgroups per launch (pe_chain_kernel) one launch in ten combined a stale partial list (batch statistics off by
+//     1e-5, sometimes garbage; found as run-to-run differences of a training iteration);
+//   * an atomic store is acknowledged by the writer's L2 and an atomic load may be served by the reader's.
+__device__ __forceinline__ void st_agent(float* p, float v) {
+    const float old = __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" ::"v"(old));             // the returned value is waited for: the exchange has been performed
+}
+__device__ __forceinline__ float ld_agent(const float* p) {
+    return __hip_atomic_fetch_add(const_cast<float*>(p), 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(double* p, double v) {
+    const double old = __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" ::"v"(old));
+}
+__device__ __forceinline__ double ld_agent(const double* p) {
+    return __hip_atomic_fetch_add(const_cast<double*>(p), 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// ticket resets by the last workgroup: also through the shared point (a plain store would sit in this XCD's L2)
+__device__ __forceinline__ void st_agent(int* p, int v) {
+    const int old = __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" ::"v"(old));
+}
+__device__ __forceinline__ void publish() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+}
 __device__ __forceinline__ void observe() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 
 // BatchNorm-backward constants of one channel from S1 = sum g, S2 = sum g * z (z the raw pre-BatchNorm value)

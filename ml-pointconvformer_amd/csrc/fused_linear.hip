@@ -187,7 +187,7 @@ __device__ __forceinline__ bool column_totals(float s1, float s2, int n0, int N,
         for (; i < gsize; ++i) a0 += ld_agent(p + (size_t)i * 2 * N);
         gsum = (a0 + a1) + (a2 + a3);
     }
-    if (threadIdx.x == 0) t1[grp] = 0;
+    if (threadIdx.x == 0) st_agent(&t1[grp], 0);
     if (groups == 1) {                              // small problems: one level, one ticket
         if (threadIdx.x < 2 * BN) sh_tot[which][cl] = (double)gsum;
         __syncthreads();
@@ -210,7 +210,7 @@ __device__ __forceinline__ bool column_totals(float s1, float s2, int n0, int N,
         }
         sh_tot[which][cl] = a0 + a1;
     }
-    if (threadIdx.x == 0) t1[FL_MAXG] = 0;
+    if (threadIdx.x == 0) st_agent(&t1[FL_MAXG], 0);
     __syncthreads();
     return true;
 }
@@ -599,7 +599,7 @@ __global__ __launch_bounds__(BLOCK) void bn_bwd_stats_kernel(const TopArgs a) {
         for (; i < gsize; ++i) a0 += ld_agent(p + (size_t)i * 2 * a.C);
         st_agent(gpart + ((size_t)grp * 2 + ty) * a.C + c, (a0 + a1) + (a2 + a3));
     }
-    if (threadIdx.x == 0) t1[grp] = 0;
+    if (threadIdx.x == 0) st_agent(&t1[grp], 0);
     publish();
     __syncthreads();
     if (threadIdx.x == 0) s_last = (atomicAdd(&t1[FL_MAXG], 1) == groups - 1) ? 1 : 0;
@@ -617,7 +617,7 @@ __global__ __launch_bounds__(BLOCK) void bn_bwd_stats_kernel(const TopArgs a) {
     __syncthreads();
     if (ty == 0 && c < a.C)
         bn_bwd_constants(a.cst, a.C, c, red[tx][0], red[TX + tx][0], (double)a.R, a.dgamma, a.dbeta, a.dbias);
-    if (threadIdx.x == 0) t1[FL_MAXG] = 0;
+    if (threadIdx.x == 0) st_agent(&t1[FL_MAXG], 0);
 }
 
 // ---- host ------------------------------------------------------------------------------------------------------------

@@ -137,9 +137,9 @@ __device__ __forceinline__ bool pass_totals(const f32x4 (&s1)[NT], const f32x4 (
         double a = 0.0;
 #pragma unroll
         for (int s = 0; s < SL; ++s) a += red[s * NV + threadIdx.x];
-        __hip_atomic_store(gpart + (size_t)grp * NV + threadIdx.x, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        st_agent(gpart + (size_t)grp * NV + threadIdx.x, a);
     }
-    if (threadIdx.x == 0) ticket[1 + grp] = 0;
+    if (threadIdx.x == 0) st_agent(ticket + 1 + grp, 0);
     publish();
     __syncthreads();
     if (threadIdx.x == 0) s_last = (atomicAdd(ticket, 1) == ngroups - 1) ? 1 : 0;
@@ -150,7 +150,7 @@ __device__ __forceinline__ bool pass_totals(const f32x4 (&s1)[NT], const f32x4 (
         double a = 0.0;
         if (sl < SL)
             for (int q = sl; q < ngroups; q += SL)
-                a += __hip_atomic_load(gpart + (size_t)q * NV + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                a += ld_agent(gpart + (size_t)q * NV + v);
         red[threadIdx.x] = a;
     }
     __syncthreads();
@@ -160,7 +160,7 @@ __device__ __forceinline__ bool pass_totals(const f32x4 (&s1)[NT], const f32x4 (
         for (int s = 0; s < SL; ++s) a += red[s * NV + threadIdx.x];
         tot[threadIdx.x] = a;
     }
-    if (threadIdx.x == 0) *ticket = 0;
+    if (threadIdx.x == 0) st_agent(ticket, 0);
     __syncthreads();
     return true;
 }

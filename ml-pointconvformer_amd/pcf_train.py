@@ -105,14 +105,18 @@ def build_edges(cfg, pointclouds, points_stored):
     return es, ef, ep, inv
 
 
-def make_optimizer(cfg, model, capturable=False):
-    """AdamW as the training script builds it (train_ScanNet_DDP_WarmUP.py:237-241), as ONE multi-tensor kernel per
-    step on the GPU (`fused=True`): the default for-each form issues ~115 launches over the 196 parameter tensors and
-    costs 5 ms of host time per iteration -- more than the GPU spends on the optimizer."""
+def make_optimizer(cfg, model, capturable=False, fused=True):
+    """AdamW as the training script builds it (train_ScanNet_DDP_WarmUP.py:237-241).  On the GPU: pcf_optim.FusedAdamW --
+    gradient norm, clipping (:421) and the update over the 196 parameter tensors in seven launches with the tensor lists
+    as kernel arguments (torch's multi-tensor AdamW + clip_grad_norm_: ~45 launches, 0.7 ms per iteration; its for-each
+    form: ~115 launches and 5 ms of host time).  `fused=False` / CPU parameters: torch.optim.AdamW."""
     params = list(model.parameters())
-    fused = all(p.is_cuda for p in params)
-    return torch.optim.AdamW(params, lr=cfg.learning_rate, weight_decay=cfg.adamw_decay, fused=fused,
-                             capturable=bool(capturable and fused))
+    on_gpu = all(p.is_cuda for p in params)
+    if fused and on_gpu:
+        import pcf_optim
+        return pcf_optim.FusedAdamW(params, lr=cfg.learning_rate, weight_decay=cfg.adamw_decay)
+    return torch.optim.AdamW(params, lr=cfg.learning_rate, weight_decay=cfg.adamw_decay, fused=on_gpu,
+                             capturable=bool(capturable and on_gpu))
 
 
 @torch.no_grad()
@@ -135,8 +139,11 @@ def training_iteration(model, optimizer, criterion, cfg, batch, edges=None):
     pred = model(features, pointclouds, es, ef, ep, norms, *inv)
     loss = criterion(pred.reshape(-1, cfg.num_classes), target)
     loss.backward()
-    clip_grad_norm_(optimizer, 10)
-    optimizer.step()
+    if hasattr(optimizer, 'last_grad_norm'):          # pcf_optim.FusedAdamW: norm, clip and update in one pass
+        optimizer.step(max_grad_norm=10)
+    else:
+        clip_grad_norm_(optimizer, 10)
+        optimizer.step()
     optimizer.zero_grad(set_to_none=True)
     return loss.detach()
 
@@ -177,5 +184,7 @@ class GraphedTrainingStep:
         if hit is None:
             hit = self.graphs[key] = self._capture(batch) + (batch,)       # keep the batch alive: the graph reads its tensors
             return hit[1]
+        if hasattr(self.optimizer, 'sync_hyperparameters'):
+            self.optimizer.sync_hyperparameters()          # a scheduler's learning rate reaches the replayed kernels
         hit[0].replay()
         return hit[1]

@@ -739,6 +739,33 @@ def test_pe_chain_against_float64_and_layer_at_a_time(device, rows, hidden, cout
     assert float(pcf_fused._tickets(device).abs().sum()) == 0.0
 
 
+def test_pe_chain_is_repeatable_with_many_short_workgroups(device):
+    """Regression: 51 973 x 16 edges = 2048 workgroups of six tiles per wave.  The hand-over of the per-workgroup partial sums
+    to the workgroup that finishes last used "atomic store, workgroup-scope fence, ticket"; that fence compiles to no
+    vector-memory wait on gfx950, the ticket overtook the store about one launch in ten, and a stale partial list entered the
+    batch statistics (csrc/flin_common.h).  Twelve runs must agree bit for bit, outputs and all parameter gradients."""
+    import pcf_fused as PF
+    torch.manual_seed(0)
+    E, H, L = 51973 * 16, 32, 32
+    rel = torch.randn(E, 3, device=device) * 0.3
+    base = [torch.randn(H, 3), torch.randn(H) * 0.1, torch.rand(H) + 0.5, torch.randn(H) * 0.1,
+            torch.randn(L, H) / H ** 0.5, torch.randn(L) * 0.1, torch.rand(L) + 0.5, torch.randn(L) * 0.1]
+    up = torch.randn(E, L, device=device)
+    first = None
+    for rep in range(12):
+        bn1, bn2 = torch.nn.BatchNorm1d(H).to(device), torch.nn.BatchNorm1d(L).to(device)
+        P = [t.clone().to(device).requires_grad_(True) for t in base]
+        out = PF._PEChain.apply((bn1, bn2), rel, *P)
+        out.backward(up)
+        got = [out.detach(), bn1.running_mean, bn2.running_var] + [p.grad for p in P]
+        if first is None:
+            first = [t.clone() for t in got]
+        else:
+            for i, (a, b) in enumerate(zip(got, first)):
+                assert torch.equal(a, b), f'run {rep}: tensor {i} differs from the first run by {float((a - b).abs().max()):.3e}'
+    assert float(PF._tickets(device).abs().sum()) == 0.0
+
+
 def test_fused_edge_chain_full_size(device):
     """BASELINE's full size (one packed cloud of 80 000 points, K = 16, 1.28 M edges): the fused three-pass backward
     (weight gradients of the first layers from moments accumulated over all edges) against the layer-at-a-time

@@ -78,6 +78,7 @@ def test_training_iteration(device, name, scenes, points):
             if hasattr(m, 'drop_path') and hasattr(m.drop_path, 'drop_prob'):
                 m.drop_path.draw = (lambda x: x.new_full((1, 1, 1), 1.0 / (1.0 - cfg.drop_path_rate)))
     loss_f, g_f = _grads(net, cfg, batch, edges, crit)
+    assert _grads(net, cfg, batch, edges, crit)[0] == loss_f, 'the forward pass (no float atomics) must repeat bit for bit'
     cfg.NO_EDGE_CHAIN = True
     for m in net.modules():
         if hasattr(m, 'no_chain') or m.__class__.__name__ == 'WeightNet':
@@ -87,3 +88,46 @@ def test_training_iteration(device, name, scenes, points):
     assert abs(loss_f - loss_l) < 1e-4 * max(1.0, abs(loss_l)), (loss_f, loss_l)
     cos = float((g_f @ g_l) / (g_f.norm() * g_l.norm()))
     assert cos > 0.99, cos
+
+
+def test_fused_adamw_with_clipping_equals_torch(device):
+    """pcf_optim.FusedAdamW.step(max_grad_norm) against clip_grad_norm_ + torch.optim.AdamW (train_ScanNet_DDP_WarmUP.py:237-241,
+    :421) over 150 tensors (three argument lists), one of them larger than a chunk, for six steps with a learning-rate change:
+    parameters, both moments, clipped gradients and the reported norm; then without clipping; state_dicts interchange."""
+    import pcf_optim
+    g = torch.Generator().manual_seed(3)
+    shapes = [(70000,), (300, 40)] + [(int(torch.randint(1, 40, (1,), generator=g)), int(torch.randint(1, 30, (1,), generator=g)))
+                                      for _ in range(148)]
+    base = [torch.randn(*s, generator=g) for s in shapes]
+    mine = [torch.nn.Parameter(t.clone().to(device)) for t in base]
+    ref = [torch.nn.Parameter(t.clone().to(device)) for t in base]
+    opt = pcf_optim.FusedAdamW(mine, lr=0.02, weight_decay=0.05)
+    want = torch.optim.AdamW(ref, lr=0.02, weight_decay=0.05)
+    for it in range(6):
+        scale = 10.0 if it % 2 == 0 else 1e-3                # clipped and unclipped steps
+        for a, b in zip(mine, ref):
+            gr = torch.randn(a.shape, generator=g).to(device) * scale
+            a.grad, b.grad = gr.clone(), gr.clone()
+        if it == 3:
+            for o in (opt, want):
+                o.param_groups[0]['lr'] = 0.005
+        clip = 10 if it < 5 else None
+        norm = torch.nn.utils.clip_grad_norm_(ref, clip) if clip else None
+        want.step()
+        opt.step(max_grad_norm=clip)
+        if clip:
+            torch.testing.assert_close(opt.last_grad_norm, norm, rtol=1e-5, atol=0)
+        for a, b in zip(mine, ref):
+            torch.testing.assert_close(a, b, rtol=2e-6, atol=2e-7)
+            torch.testing.assert_close(a.grad, b.grad, rtol=2e-6, atol=1e-9)
+            torch.testing.assert_close(opt.state[a]['exp_avg'], want.state[b]['exp_avg'], rtol=2e-6, atol=1e-8)
+            torch.testing.assert_close(opt.state[a]['exp_avg_sq'], want.state[b]['exp_avg_sq'], rtol=2e-6, atol=1e-12)
+        assert float(opt.state[mine[0]]['step']) == it + 1
+    sd = opt.state_dict()
+    again = pcf_optim.FusedAdamW(mine, lr=0.02, weight_decay=0.05)
+    again.load_state_dict(sd)
+    torch.optim.AdamW(ref, lr=0.02, weight_decay=0.05).load_state_dict(sd)          # torch accepts the same layout
+    for a in mine:
+        a.grad = torch.ones_like(a)
+    again.step()
+    assert float(again.state[mine[0]]['step']) == 7
