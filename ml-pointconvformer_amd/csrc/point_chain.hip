@@ -496,20 +496,36 @@ struct TailArgs {
 // Weight fragments of a [rows, cols] matrix (both multiples of 16) into LDS, read with coalesced 16-byte loads.
 //   plain:      fragment (n = o / 16, k = c / 16) at index n * (cols / 16) + k, lane (p = o % 16, g = c % 16 / 4), s = c % 4
 //   transposed: fragment (k = c / 16, n = o / 16) at index k * (rows / 16) + n, lane (p = c % 16, g = o % 16 / 4), s = o % 4
-__device__ __forceinline__ void stage_matrix(float4* wl, const float* W, int rows, int cols, bool transposed) {
-    const int c4s = cols / 4;
-    float* wf = reinterpret_cast<float*>(wl);
-    for (int i = threadIdx.x; i < rows * c4s; i += BLOCK) {
-        const int o = i / c4s, c = 4 * (i % c4s);
-        const float4 v = ld4(W + (size_t)o * cols + c);
-        if (!transposed) {
-            wl[((o >> 4) * (cols >> 4) + (c >> 4)) * WAVE + ((c & 15) >> 2) * 16 + (o & 15)] = v;
-        } else {
-            float* dst = wf + ((size_t)(((c >> 4) * (rows >> 4) + (o >> 4)) * WAVE + ((o & 15) >> 2) * 16 + (c & 15))) * 4 + (o & 3);
-            dst[0] = v.x; dst[4] = v.y; dst[8] = v.z; dst[12] = v.w;
+// Two halves, so that the loads of all units are in flight together and a tile prefetch can be issued between them: the
+// loads return in order, and waiting for the staging loads does not wait for the prefetch behind them.
+template <int ROWS, int COLS>
+struct StagedMatrix {
+    static constexpr int UNITS = ROWS * COLS / 4, NV = (UNITS + BLOCK - 1) / BLOCK;
+    float4 v[NV];
+    __device__ __forceinline__ void load(const float* W) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int u = threadIdx.x + i * BLOCK;
+            v[i] = (UNITS % BLOCK == 0 || u < UNITS) ? ld4(W + (size_t)u * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
-}
+    __device__ __forceinline__ void store(float4* wl, bool transposed) const {
+        constexpr int C4 = COLS / 4;
+        float* wf = reinterpret_cast<float*>(wl);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int u = threadIdx.x + i * BLOCK;
+            if (UNITS % BLOCK != 0 && u >= UNITS) break;
+            const int o = u / C4, c = 4 * (u % C4);
+            if (!transposed) {
+                wl[((o >> 4) * (COLS >> 4) + (c >> 4)) * WAVE + ((c & 15) >> 2) * 16 + (o & 15)] = v[i];
+            } else {
+                float* dst = wf + ((size_t)(((c >> 4) * (ROWS >> 4) + (o >> 4)) * WAVE + ((o & 15) >> 2) * 16 + (c & 15))) * 4 + (o & 3);
+                dst[0] = v[i].x; dst[4] = v[i].y; dst[8] = v[i].z; dst[12] = v[i].w;
+            }
+        }
+    }
+};
 
 // The tile loops below are software-pipelined by hand: the loads of a wave's first tile are issued in front of the weight
 // staging, those of its next tile in front of the current tile's matrix products (a wave has two or three tiles, and one or
@@ -527,13 +543,14 @@ __global__ __launch_bounds__(BLOCK) void tail_fwd_kernel(const TailArgs a) {
     const long long ntiles = (a.R + 15) / 16, stride = (long long)gridDim.x * NWAVE;
     long long t = (long long)blockIdx.x * NWAVE + wave_id();
     const float* in = PASS == 1 ? a.agg : a.z3;
+    StagedMatrix<PASS == 1 ? CH3 : CO, PASS == 1 ? CA : CH3> wst;
+    wst.load(PASS == 1 ? a.W3 : a.W4);
     f32x4 nxt[NIN];
     if (t < ntiles) {
 #pragma unroll
         for (int i = 0; i < NIN; ++i) nxt[i] = ld_row4(in, t * 16 + p, a.R, 16 * NIN, 16 * i + 4 * g);
     }
-    if (PASS == 1) stage_matrix(wl, a.W3, CH3, CA, false);
-    else stage_matrix(wl, a.W4, CO, CH3, false);
+    wst.store(wl, false);
     f32x4 s1[NS], s2[NS];
 #pragma unroll
     for (int i = 0; i < NS; ++i) { s1[i] = zero4; s2[i] = zero4; }
@@ -632,10 +649,11 @@ __global__ __launch_bounds__(BLOCK) void tail_bwd_kernel(const TailArgs a) {
             }
         }
     };
+    StagedMatrix<PASS == 3 ? CH3 : CO, PASS == 3 ? CA : CH3> wst;
+    if (PASS >= 2) wst.load(PASS == 3 ? a.W3 : a.W4);
     f32x4 nxt[NIN];
     if (t < ntiles) load_tile(t, nxt);
-    if (PASS == 2) stage_matrix(wl, a.W4, CO, CH3, true);
-    if (PASS == 3) stage_matrix(wl, a.W3, CH3, CA, true);
+    if (PASS >= 2) wst.store(wl, true);
     float* tb = tbuf + wave * NTB * 16 * PT;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     constexpr int NS = PASS == 1 ? NO : NH;
@@ -776,11 +794,13 @@ __global__ __launch_bounds__(BLOCK) void pe_chain_kernel(const PeArgs a) {
             for (int nl = 0; nl < NL; ++nl) d[nl] = ld_row4(a.dout, tt * 16 + p, a.R, CL, 16 * nl + 4 * g);
         }
     };
+    StagedMatrix<CL, CH> wst;
+    if (L2) wst.load(a.W2);
     float xn = 0.f;
     f32x4 dn[ND];
     if (t < ntiles) { xn = load_x(t); load_d(t, dn); }
-    if (L2) stage_matrix(wl, a.W2, CL, CH, false);
-    if (TR) stage_matrix(wt, a.W2, CL, CH, true);
+    if (L2) wst.store(wl, false);
+    if (TR) wst.store(wt, true);
     float* tb = tbuf + wave * NTB * 16 * PT;
     float w1[NH];
     f32x4 bias1[NH], sc1[NH], sh1[NH], d11[NH], d01[NH], bias2[NL], sc2[NL], sh2[NL], d12[NL], d02[NL];
