@@ -75,6 +75,9 @@ int pcf_hip_set_chain_backward_engine(int lds_transposes);
  * Activation codes: 0 none, 1 ReLU, 2 LeakyReLU(0.1), 3 sigmoid. */
 size_t pcf_hip_flin_workspace_bytes(long long rows, int c_out, int c_in);
 int pcf_hip_flin_ticket_ints(void);
+/* pcf_hip_flin_forward / _backward_input have a split-K form (32 x 32 tiles, the four waves of a workgroup share the
+ * contraction) for few rows and long contractions; mode -1: chosen by size (default), 0: never, 1: wherever K >= 64. */
+int pcf_hip_set_flin_split_k(int mode);
 /* Z[M,N] = f(A)[M,K] W[N,K]^T + bias, f = act_pre(A * pre[0] + pre[1]) when `pre` (the producer's record) is given, else
  * identity; `side` (nullable) receives f(A).  cst != null: batch statistics of Z -> cst rows 0..3 and the running
  * statistics (momentum update with the unbiased variance, as nn.BatchNorm1d). */

@@ -43,7 +43,9 @@ template <int ROWS, bool KCONT, int KS = FK>
 struct Tile {
     static constexpr int UNITS = ROWS * KS / 4;
     static constexpr int NV = (UNITS + BLOCK - 1) / BLOCK;
-    static constexpr int STRIDE = ROWS + 4;
+    // LDS row stride.  KCONT tiles are written with scalar stores, 16 lanes of a wave along k at KS = 64 (4 at KS = 16):
+    // stride = 1 (mod 32) spreads those over all banks, where ROWS + 4 would put the 16 on two.
+    static constexpr int STRIDE = (KCONT && KS >= 64) ? ROWS + 1 : ROWS + 4;
     float4 v[NV];
 
     __device__ __forceinline__ static bool unit(int i, int& r, int& k) {
@@ -321,6 +323,107 @@ __global__ __launch_bounds__(BLOCK) void flin_fwd_kernel(const FwdArgs g) {
     }
 }
 
+// Few rows, long contraction (the coarse levels of the models: 40-700 tiles of 64 x 64, K up to 1536): a launch is bound by
+// the serial matrix work of ONE workgroup (K / 2 products of 64 cycles per wave), not by memory.  Split-K form: a 32 x 32
+// tile per workgroup (4 x the workgroups), 64 contraction elements staged per step of which each of the four waves takes 16,
+// the four accumulators summed through LDS in wave order (deterministic), then the usual epilogue with one thread per four
+// outputs.  Same arguments, statistics and ticket layout as flin_fwd_kernel (column tiles are 32 wide).
+constexpr int SK = 64;
+template <int STRIDE_A, int STRIDE_B>
+__device__ __forceinline__ f32x16 mfma_quarter(const float* sA, const float* sB, int wave, int lane, f32x16 acc) {
+    const float* pa = sA + (lane & 31);
+    const float* pb = sB + (lane & 31);
+    const int k0 = wave * (SK / NWAVE) + (lane >> 5);
+#pragma unroll
+    for (int kk = 0; kk < SK / NWAVE; kk += 2)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[(k0 + kk) * STRIDE_A], pb[(k0 + kk) * STRIDE_B], acc, 0, 0, 0);
+    return acc;
+}
+// the four waves' 32 x 32 accumulators -> sums of four outputs per thread: rows (threadIdx.x >> 5) + 8 i, column threadIdx.x & 31
+__device__ __forceinline__ void reduce_quarters(f32x16 acc, float (*sred)[32 * 33], float (&out)[4]) {
+    const int lane = lane_id(), wave = wave_id();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sred[wave][((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 33 + (lane & 31)] = acc[r];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int o = ((threadIdx.x >> 5) + 8 * i) * 33 + (threadIdx.x & 31);
+        out[i] = (sred[0][o] + sred[1][o]) + (sred[2][o] + sred[3][o]);
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(BLOCK) void flin_fwd_sk_kernel(const FwdArgs g) {
+    using TA = Tile<32, true, SK>;
+    using TB = Tile<32, true, SK>;
+    __shared__ __align__(16) float sA[SK * TA::STRIDE];
+    __shared__ __align__(16) float sB[SK * TB::STRIDE];
+    __shared__ float sred[NWAVE][32 * 33];
+    __shared__ double sh_tot[2][32];
+    const int n0 = blockIdx.x * 32;
+    const int wave = wave_id(), lane = lane_id();
+    const int mtiles = ceil_div_dev(g.M, 32);
+    const int col = n0 + (threadIdx.x & 31);
+    const float bv = (g.bias && col < g.N) ? g.bias[col] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    TA ta;
+    TB tb;
+    auto load_a = [&](int m0, int k0) {
+#pragma unroll
+        for (int i = 0; i < TA::NV; ++i) {
+            int r, k;
+            if (!TA::unit(i, r, k)) break;
+            float4 t = TA::template fetch<true>(g.A, g.K, m0 + r, k0 + k, g.M, g.K);
+            if (g.pre) {
+                t = affine_act4(t, cst4(g.pre, k0 + k, g.K), cst4(g.pre + g.K, k0 + k, g.K), g.pre_act);
+                if (g.side && blockIdx.x == 0 && m0 + r < g.M && k0 + k + 3 < g.K) st4(g.side + (size_t)(m0 + r) * g.K + k0 + k, t);
+            }
+            ta.v[i] = t;
+        }
+    };
+    auto load_b = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < TB::NV; ++i) {
+            int r, k;
+            if (!TB::unit(i, r, k)) break;
+            tb.v[i] = TB::template fetch<true>(g.W, g.K, n0 + r, k0 + k, g.N, g.K);
+        }
+    };
+    for (int mt = blockIdx.y; mt < mtiles; mt += gridDim.y) {
+        const int m0 = mt * 32;
+        f32x16 acc = {0};
+        load_a(m0, 0);
+        load_b(0);
+        for (int k0 = 0; k0 < g.K; k0 += SK) {
+            __syncthreads();
+            ta.store(sA);
+            tb.store(sB);
+            __syncthreads();
+            if (k0 + SK < g.K) { load_a(m0, k0 + SK); load_b(k0 + SK); }
+            acc = mfma_quarter<TA::STRIDE, TB::STRIDE>(sA, sB, wave, lane, acc);
+        }
+        float o[4];
+        reduce_quarters(acc, sred, o);
+        if (col < g.N) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = m0 + (threadIdx.x >> 5) + 8 * i;
+                if (row < g.M) {
+                    const float v = o[i] + bv;
+                    g.Z[(size_t)row * g.N + col] = v;
+                    s1 += v;
+                    s2 += v * v;
+                }
+            }
+        }
+    }
+    if (!g.cst) return;
+    if (!column_totals<4, 1>(s1, s2, n0, g.N, g.part, g.ticket, sh_tot)) return;
+    if (threadIdx.x < 32 && n0 + threadIdx.x < g.N)
+        bn_fwd_constants(g.cst, g.N, n0 + threadIdx.x, sh_tot[0][threadIdx.x], sh_tot[1][threadIdx.x], (double)g.M, g.gamma, g.beta,
+                         g.running_mean, g.running_var, g.eps, g.momentum);
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 struct BwdInArgs {
     const float* dy; const float* z;     // [M, K]: gradient w.r.t. this layer's activated output, its raw output
@@ -408,6 +511,85 @@ __global__ __launch_bounds__(BLOCK) void flin_bwd_in_kernel(const BwdInArgs g) {
     if (!g.cstp) return;
     if (!column_totals<WM, WN>(s1, s2, n0, g.N, g.part, g.ticket, sh_tot)) return;
     if (threadIdx.x < BN && n0 + threadIdx.x < g.N)
+        bn_bwd_constants(g.cstp, g.N, n0 + threadIdx.x, sh_tot[0][threadIdx.x], sh_tot[1][threadIdx.x], (double)g.M, g.dgamma_p, g.dbeta_p, g.dbias_p);
+}
+
+// split-K form of flin_bwd_in_kernel (see flin_fwd_sk_kernel)
+__global__ __launch_bounds__(BLOCK) void flin_bwd_in_sk_kernel(const BwdInArgs g) {
+    using TA = Tile<32, true, SK>;
+    using TB = Tile<32, false, SK>;
+    __shared__ __align__(16) float sA[SK * TA::STRIDE];
+    __shared__ __align__(16) float sB[SK * TB::STRIDE];
+    __shared__ float sred[NWAVE][32 * 33];
+    __shared__ double sh_tot[2][32];
+    const int n0 = blockIdx.x * 32;
+    const int wave = wave_id(), lane = lane_id();
+    const int mtiles = ceil_div_dev(g.M, 32);
+    const int col = n0 + (threadIdx.x & 31);
+    float scp = 0.f, shp = 0.f;
+    if (g.cstp && col < g.N) { scp = g.cstp[col]; shp = g.cstp[g.N + col]; }
+    float s1 = 0.f, s2 = 0.f;
+    TA ta;
+    TB tb;
+    auto load_a = [&](int m0, int k0) {
+#pragma unroll
+        for (int i = 0; i < TA::NV; ++i) {
+            int r, k;
+            if (!TA::unit(i, r, k)) break;
+            const int gk = k0 + k;
+            const float4 dy = TA::template fetch<true>(g.dy, g.K, m0 + r, gk, g.M, g.K);
+            const float4 z = TA::template fetch<true>(g.z, g.K, m0 + r, gk, g.M, g.K);
+            float4 t = dz4(dy, z, cst4(g.cst, gk, g.K), cst4(g.cst + g.K, gk, g.K), cst4(g.cst + 4 * g.K, gk, g.K),
+                           cst4(g.cst + 5 * g.K, gk, g.K), g.act);
+            const bool rv = m0 + r < g.M;
+            ta.v[i] = mask4(t, rv && gk < g.K, rv && gk + 1 < g.K, rv && gk + 2 < g.K, rv && gk + 3 < g.K);
+        }
+    };
+    auto load_b = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < TB::NV; ++i) {
+            int r, k;
+            if (!TB::unit(i, r, k)) break;
+            tb.v[i] = TB::template fetch<true>(g.W, g.N, n0 + r, k0 + k, g.N, g.K);
+        }
+    };
+    for (int mt = blockIdx.y; mt < mtiles; mt += gridDim.y) {
+        const int m0 = mt * 32;
+        f32x16 acc = {0};
+        load_a(m0, 0);
+        load_b(0);
+        for (int k0 = 0; k0 < g.K; k0 += SK) {
+            __syncthreads();
+            ta.store(sA);
+            tb.store(sB);
+            __syncthreads();
+            if (k0 + SK < g.K) { load_a(m0, k0 + SK); load_b(k0 + SK); }
+            acc = mfma_quarter<TA::STRIDE, TB::STRIDE>(sA, sB, wave, lane, acc);
+        }
+        float o[4];
+        reduce_quarters(acc, sred, o);
+        if (col < g.N) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = m0 + (threadIdx.x >> 5) + 8 * i;
+                if (row < g.M) {
+                    const size_t off = (size_t)row * g.N + col;
+                    float v = o[i];
+                    if (g.add) v += g.add[off];
+                    g.dx[off] = v;
+                    if (g.cstp) {
+                        const float zp = g.zp[off];
+                        const float gp = v * fl_dact(g.actp, zp * scp + shp);
+                        s1 += gp;
+                        s2 += gp * zp;
+                    }
+                }
+            }
+        }
+    }
+    if (!g.cstp) return;
+    if (!column_totals<4, 1>(s1, s2, n0, g.N, g.part, g.ticket, sh_tot)) return;
+    if (threadIdx.x < 32 && n0 + threadIdx.x < g.N)
         bn_bwd_constants(g.cstp, g.N, n0 + threadIdx.x, sh_tot[0][threadIdx.x], sh_tot[1][threadIdx.x], (double)g.M, g.dgamma_p, g.dbeta_p, g.dbias_p);
 }
 
@@ -626,6 +808,16 @@ static inline int rows_grid(int mtiles, int xtiles) {
     return std::max(1, std::min({mtiles, want, FL_MAXY}));
 }
 static inline bool vec_ok(const void* p, long long ld) { return aligned16(p) && ld % 4 == 0; }
+// the split-K kernels: fewer than two 64 x 64 (128 x 32 for narrow outputs) tiles per CU and a contraction long enough for
+// the serial matrix work to dominate (pcf_hip_set_flin_split_k: 0 / 1 force them off / on where they apply, -1 = this rule)
+static int g_split_k = -1;
+static inline bool split_k_pays(long long M, int N, int K) {
+    const int force = g_split_k;
+    if (force == 0) return false;
+    const long long tiles = N <= 32 ? (long long)ceil_div(M, 128) : (long long)ceil_div(M, 64) * ceil_div(N, 64);
+    if (force == 1) return K >= 64;
+    return K >= 128 && tiles <= 512;
+}
 // row ranges of the weight gradient: ~1024 workgroups overall, at least 4 steps each, at most BW_SPLITS_MAX slabs and 32 MB
 // of them.  Layers with at most 32 output channels use 32 x 128 tiles.
 static inline bool bw_narrow(int M) { return M <= 32; }
@@ -654,6 +846,11 @@ size_t pcf_hip_flin_workspace_bytes(long long rows, int c_out, int c_in) {
     return std::max(partials, slabs) + 256;
 }
 int pcf_hip_flin_ticket_ints(void) { return 8192; }
+int pcf_hip_set_flin_split_k(int mode) {
+    if (mode < -1 || mode > 1) return pcf::fail(PCF_E_BADARG, "set_flin_split_k: mode is -1 (automatic), 0 (off) or 1 (on)");
+    pcf::g_split_k = mode;
+    return pcf::ok();
+}
 
 int pcf_hip_flin_forward(const float* A, long long M, int K, const float* pre, int pre_act, float* side, const float* W,
                          const float* bias, int N, float* Z, float* cst, const float* gamma, const float* beta,
@@ -672,6 +869,12 @@ int pcf_hip_flin_forward(const float* A, long long M, int K, const float* pre, i
     g.gamma = gamma; g.beta = beta; g.running_mean = running_mean; g.running_var = running_var; g.eps = eps; g.momentum = momentum;
     const bool vec = vec_ok(A, K) && vec_ok(W, K) && (!side || vec_ok(side, K)) && (!pre || vec_ok(pre, K));
     hipStream_t s = (hipStream_t)stream;
+    if (vec && split_k_pays(M, N, K)) {
+        const int xt = ceil_div(N, 32);
+        PCF_REQUIRE(xt * (FL_MAXG + 1) <= pcf_hip_flin_ticket_ints(), "flin_forward: too many output channels");
+        hipLaunchKernelGGL(flin_fwd_sk_kernel, dim3(xt, rows_grid(ceil_div(M, 32), xt)), dim3(BLOCK), 0, s, g);
+        return check_launch("flin_fwd_sk_kernel");
+    }
     if (N <= 32) {
         dim3 grid(1, rows_grid(ceil_div(M, 128), 1));
         if (vec) hipLaunchKernelGGL((flin_fwd_kernel<4, 1, true>), grid, dim3(BLOCK), 0, s, g);
@@ -701,6 +904,12 @@ int pcf_hip_flin_backward_input(const float* dy, const float* z, const float* cs
     g.M = (int)M; g.N = N; g.K = K;
     const bool vec = vec_ok(dy, K) && vec_ok(z, K) && vec_ok(W, N) && vec_ok(cst, K);
     hipStream_t s = (hipStream_t)stream;
+    if (vec && split_k_pays(M, N, K)) {
+        const int xt = ceil_div(N, 32);
+        PCF_REQUIRE(xt * (FL_MAXG + 1) <= pcf_hip_flin_ticket_ints(), "flin_backward_input: too many input channels");
+        hipLaunchKernelGGL(flin_bwd_in_sk_kernel, dim3(xt, rows_grid(ceil_div(M, 32), xt)), dim3(BLOCK), 0, s, g);
+        return check_launch("flin_bwd_in_sk_kernel");
+    }
     if (N <= 32) {
         dim3 grid(1, rows_grid(ceil_div(M, 128), 1));
         if (vec) hipLaunchKernelGGL((flin_bwd_in_kernel<4, 1, true>), grid, dim3(BLOCK), 0, s, g);

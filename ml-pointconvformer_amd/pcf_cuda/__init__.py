@@ -118,6 +118,12 @@ def read_launch_log():
     return [l for l in buf.value.decode().split('\n') if l]
 
 
+def set_flin_split_k(mode: int):
+    """-1: the split-K form of the point-level Linear+BN products where it pays (default); 0: never; 1: wherever it applies."""
+    if _lib.pcf_hip_set_flin_split_k(int(mode)) != 0:
+        raise RuntimeError(_last_error().decode())
+
+
 def set_aggregate_engine(name: str):
     """'default' | 'lds' | 'tiled': the kernel family behind pcf_forward/backward and pconv_* for the shapes the
     matrix-core kernels cover (process-wide; the cross-checks of the test-suite toggle it)."""
