@@ -377,8 +377,10 @@ def main():
                          'the eager step is marginally host-bound -- ~190 launches in 1.6 ms -- and slows down by '
                          '5-15 %% in the first process of a fresh box)')
     ap.add_argument('--graph', action='store_true',
-                    help='insist on HIP-graph replay (a failed capture is an error instead of a fall-back); with N > 1 GPUs: '
-                         'replayed steps + one flat-bucket all-reduce instead of eager steps under DistributedDataParallel')
+                    help='insist on HIP-graph replay (a failed capture is an error instead of a fall-back; with N > 1 GPUs '
+                         'the replay-versus-eager trial is skipped)')
+    ap.add_argument('--ddp', action='store_true',
+                    help='N > 1: eager steps under torch DistributedDataParallel instead of the flat gradient bucket')
     ap.add_argument('--deterministic', action='store_true',
                     help='grad_x by CSR gather-reduce (bitwise reproducible) instead of float atomics')
     args = ap.parse_args()
@@ -431,11 +433,13 @@ def main():
     csr_ms = (time.perf_counter() - t0) * 1e3
 
     params = list(layer.parameters())        # walking the module tree every step costs ~0.1 ms of host time
-    # N > 1: one flat bucket of the 13.7 k gradient floats, packed inside the replayed graph, one RCCL all-reduce and
-    # one multi-tensor copy back per step (DDP's per-step hooks need eager launches: ~20 % slower steps)
-    # N > 1 default: eager steps under DistributedDataParallel -- the path that is standard and has met RCCL; the replayed
-    # graph + flat bucket (three host calls per step) is opt-in with --graph until it has been run on a multi-GPU node
-    bucket = pcf_dist.GradBucket(params, list(layer.buffers())) if (world > 1 and args.graph and not args.no_graph) else None
+    # N > 1: one flat bucket of the 13.7 k gradient floats (packed inside the replayed graph), one RCCL all-reduce and one
+    # multi-tensor copy back per step: three host calls.  DistributedDataParallel's per-step hooks need eager launches (the
+    # eager step is host-bound: ~1.25 ms against 1.0 ms replayed) -- `--ddp` times that standard path instead.  Whether the
+    # steps are replayed or launched eagerly is decided by a short trial below (both use the bucket; the choice is agreed
+    # across the ranks), so a node where replay + collective interact badly still gets a valid, eager, number.
+    use_ddp = world > 1 and (args.ddp or args.no_graph)
+    bucket = pcf_dist.GradBucket(params, list(layer.buffers())) if (world > 1 and not use_ddp) else None
     if bucket is not None:
         bucket.broadcast_parameters()
     elif world > 1:
@@ -504,6 +508,20 @@ def main():
             for _ in range(3):
                 replay_step()
             torch.cuda.synchronize()
+        if captured and world > 1 and not args.graph:
+            # trial: 8 replayed against 8 eager steps, slowest rank counts; replay has to win to be used
+            trial = []
+            for fn in (replay_step, eager_step):
+                pcf_dist.fence(dev)
+                t0 = time.perf_counter()
+                for _ in range(8):
+                    fn()
+                pcf_dist.fence(dev)
+                trial.append(pcf_dist.max_over_ranks(time.perf_counter() - t0, dev))
+            captured = trial[0] <= trial[1]
+            if rank == 0:
+                print(f'bench: trial of 8 steps: replay {trial[0] * 125:.3f} ms/step, eager {trial[1] * 125:.3f} ms/step -> '
+                      f'{"replay" if captured else "eager"}', file=sys.stderr)
         if captured:
             graph, step = g, replay_step
         else:
