@@ -1092,7 +1092,7 @@ def point_head(x, unary1, guidance_unary, Wa):
         l1 = unary1.mlp
         bn1 = l1.bn
         args += [l1.c.weight, l1.c.bias, l1.bn.weight, l1.bn.bias]
-        if bn1.eps == l2.bn.eps and Wa.shape[0] == 8 and \
+        if x.numel() > 0 and bn1.eps == l2.bn.eps and Wa.shape[0] == 8 and \
                 point_head_chain_supported(l1.c.in_features, l1.c.out_features, l2.c.out_features):
             return _PointHeadChain.apply((bn1, l2.bn), x.contiguous(), *args)      # narrow widths: the row chain
     return _PointHead.apply((bn1, l2.bn), x.contiguous(), *args)
@@ -1103,7 +1103,7 @@ def point_tail(agg, shortcut, linear, unary2):
     _floats(agg=agg, shortcut=shortcut)
     l4 = unary2.mlp
     fn = _PointTail
-    if linear.bn.eps == l4.bn.eps and point_tail_chain_supported(linear.c.in_features, linear.c.out_features, l4.c.out_features):
+    if agg.numel() > 0 and linear.bn.eps == l4.bn.eps and point_tail_chain_supported(linear.c.in_features, linear.c.out_features, l4.c.out_features):
         fn = _PointTailChain                                                     # BASELINE widths: the row chain
     return fn.apply((linear.bn, l4.bn), agg.contiguous(), shortcut.contiguous(), linear.c.weight, linear.c.bias,
                             linear.bn.weight, linear.bn.bias, l4.c.weight, l4.c.bias, l4.bn.weight, l4.bn.bias)

@@ -319,7 +319,7 @@ class WeightNet(pcf_fused.CounterScope):
                                                         convs[2].c.out_features, w.numel() // max(1, w.shape[-1])):
             # the three layers in one fused chain (four passes forward, three backward; csrc/edge_chain*.hip)
             return pcf_fused.weightnet_chain(w, [(m.c, m.bn) for m in convs], self.training)
-        if len(convs) == 2 and self.training and not w.requires_grad and not getattr(self, 'no_chain', False) \
+        if len(convs) == 2 and self.training and w.numel() > 0 and not w.requires_grad and not getattr(self, 'no_chain', False) \
                 and pcf_fused.point_chain_ok(convs[0].bn, convs[1].bn) and convs[0].bn.eps == convs[1].bn.eps \
                 and pcf_fused.pe_chain_supported(convs[0].c.in_features, (convs[0].c.out_features,), convs[1].c.out_features):
             # pe_convs (3 -> out/4 -> min(out/4, 32)): both layers per pass, nothing but the output stored
