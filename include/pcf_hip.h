@@ -481,6 +481,24 @@ int pcf_hip_pcf_chain_backward(const float* vi, const int64_t* idx, const float*
                                float* const* db, float* const* dgamma, float* const* dbeta, void* workspace,
                                size_t workspace_bytes, void* stream);
 
+/* Strided PCFLayers (layers.py:372-375): key = maximum of the query over the neighbourhood instead of neighbour 0.  ukey
+ * [E / K, 8] = Wa . max_k guidance_x[idx[n, k]] is the gathered half of that key, formed per centre by the caller (K >= 2);
+ * the positional half is taken inside the kernels.  The backward adds dukey [E / K, 8]; both forms share every kernel. */
+int pcf_hip_pcf_chain_forward_maxkey(const float* ukey, const float* vi, const int64_t* idx, const float* u, long long E,
+                                     long long rows_per_batch, int N, int K, int cv, int g, int heads, int cm,
+                                     const float* const* W, const float* const* b, const float* const* gamma,
+                                     const float* const* beta, float* const* running_mean, float* const* running_var,
+                                     float eps, float momentum, int batch_stats, float* stats, float* pe, float* a1, float* h1,
+                                     float* a2, float* h1_acc, float* a2_acc, float* score, float* w, void* workspace,
+                                     size_t workspace_bytes, void* stream);
+int pcf_hip_pcf_chain_backward_maxkey(const float* ukey, float* dukey, const float* vi, const int64_t* idx, const float* h1_acc,
+                                      const float* a2_acc, const float* dscore, const float* dw, long long E,
+                                      long long rows_per_batch, int N, int K, int cv, int g, int heads, int cm,
+                                      const float* const* W, const float* const* b, const float* const* gamma,
+                                      const float* const* beta, const float* stats, float* du, float* const* dW,
+                                      float* const* db, float* const* dgamma, float* const* dbeta, void* workspace,
+                                      size_t workspace_bytes, void* stream);
+
 /* WeightNet alone (layers.py:127-191: Linear_BN + ReLU x 3, cin -> 8 -> 8 -> C_mid), the branch every PointConv-family
  * layer feeds its aggregate with: same kernels as the WeightNet branch of the fused PCFLayer edge graph, no
  * neighbourhood structure needed (strided / transposed / any K).  x [E, cin] (cin <= 12), E % 16 == 0, C_mid <= 16.

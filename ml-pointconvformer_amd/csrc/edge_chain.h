@@ -28,6 +28,10 @@ struct ChainArgs {
     float* h1_acc; float* a2_acc;   // [E, 8] raw accumulators (pre-BatchNorm, bias not added) of g1 and w2, for the fused backward
     float* part;                // [blocks][2][64] partial sums of the pass
     int vec_vi;
+    // Strided layers (layers.py:372-375): the key is the MAXIMUM of the query over the neighbourhood instead of neighbour 0.
+    // Non-null ukey selects that form: ukey [centres, 8] = Wa . max_k guidance_x[idx[n, k]] (the gathered half, formed per
+    // centre by the caller); the positional half Wb . max_k pe[n, k] is taken over the K lanes of the neighbourhood (2 <= K).
+    const float* ukey;
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -69,6 +73,27 @@ struct BatchWalk {
 };
 
 #define PCF_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_16x16x4f32((A), (B), (C), 0, 0, 0)
+
+// reductions over lanes of a row (the 16 edges of a tile, one register each): DPP only, every lane gets the result
+template <int CTRL> __device__ __forceinline__ float row_dpp(float v) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, 0xf, 0xf, true));
+}
+// over the K consecutive lanes of a neighbourhood (K a power of two, 2..16; groups are K-aligned)
+__device__ __forceinline__ float nbr_max(float v, int K) {
+    v = fmaxf(v, row_dpp<0xB1>(v));                      // quad_perm [1,0,3,2]
+    if (K >= 4) v = fmaxf(v, row_dpp<0x4E>(v));          // quad_perm [2,3,0,1]
+    if (K >= 8) v = fmaxf(v, row_dpp<0x141>(v));         // row_half_mirror
+    if (K >= 16) v = fmaxf(v, row_dpp<0x140>(v));        // row_mirror
+    return v;
+}
+__device__ __forceinline__ float nbr_min(float v, int K) {
+    v = fminf(v, row_dpp<0xB1>(v));
+    if (K >= 4) v = fminf(v, row_dpp<0x4E>(v));
+    if (K >= 8) v = fminf(v, row_dpp<0x141>(v));
+    if (K >= 16) v = fminf(v, row_dpp<0x140>(v));
+    return v;
+}
+__device__ __forceinline__ f32x4 nbr_max(f32x4 v, int K) { return f32x4{nbr_max(v[0], K), nbr_max(v[1], K), nbr_max(v[2], K), nbr_max(v[3], K)}; }
 
 // up to 4 workgroups per CU; every wave walks tiles with a grid stride
 inline int chain_grid(long long E) {

@@ -175,8 +175,23 @@ __global__ __launch_bounds__(BLOCK) void pcf_chain_kernel(const ChainArgs a) {
         for (int r = 0; r < 4; ++r) h1[r] += h1b[r];
 #pragma unroll
         for (int r = 0; r < 4; ++r) h1[r] += ucur[r];
+        if (a.ukey) {
+            // strided: key = maximum of the query over the neighbourhood; Wb . max pe here, Wa . max gx in ukey
+            const f32x4 pm0 = nbr_max(pe0, a.K), pm1 = nbr_max(pe1, a.K);
+            f32x4 hk = zero4, hkb = zero4;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) h1[r] -= __shfl(h1[r], lead, WAVE);
+            for (int s = 0; s < 4; ++s) {
+                hk = PCF_MFMA(w_g1[0][s], pm0[s], hk);
+                hkb = PCF_MFMA(w_g1[1][s], pm1[s], hkb);
+            }
+            f32x4 uk = zero4;
+            if (g < 2) { const float4 v = ld4(a.ukey + (size_t)(e / a.K) * CH + 4 * g); uk[0] = v.x; uk[1] = v.y; uk[2] = v.z; uk[3] = v.w; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h1[r] -= (hk[r] + hkb[r]) + uk[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h1[r] -= __shfl(h1[r], lead, WAVE);
+        }
         if (LEVEL == 2) {
             // the raw accumulators of g1 / w2: passes 3, 4 and the fused backward restart from them
             if (g < 2) {
@@ -479,13 +494,15 @@ size_t pcf_hip_pcf_chain_workspace_bytes(void) { return (size_t)2048 * 96 * 4 + 
 // stats [12][64] floats (device): mean of layer l at stats + l*64, rstd at stats + (6 + l)*64, l in the
 // order mlp_conv, g1, g2, w1, w2, w3.  Training (batch_stats != 0): computed here and the running
 // statistics (nullable) updated; inference: the caller fills them from the running statistics.
-int pcf_hip_pcf_chain_forward(const float* vi, const int64_t* idx, const float* u, long long E, long long rows_per_batch,
+static int chain_forward_impl(const float* ukey, const float* vi, const int64_t* idx, const float* u, long long E, long long rows_per_batch,
                               int N, int K, int cv, int g, int heads, int cm, const float* const* W, const float* const* b,
                               const float* const* gamma, const float* const* beta, float* const* running_mean,
                               float* const* running_var, float eps, float momentum, int batch_stats, float* stats,
                               float* pe, float* a1, float* h1, float* a2, float* h1_acc, float* a2_acc, float* score,
                               float* w, void* workspace, size_t workspace_bytes, void* stream) {
     using namespace pcf;
+    if (ukey && (K < 2 || !aligned16(ukey)))
+        return fail(PCF_E_UNSUPPORTED, "pcf_chain (maximum key): K >= 2 and a 16-byte aligned ukey (K=%d)", K);
     PCF_REQUIRE(E >= 0 && rows_per_batch > 0 && N >= 0, "pcf_chain: bad sizes");
     if (cv < 1 || cv > CV || g < 1 || g > CG || heads < 1 || heads > CHD || cm < 1 || cm > CMX)
         return fail(PCF_E_UNSUPPORTED, "pcf_chain: widths outside the fused kernel (cv=%d<=12, g=%d<=32, heads=%d<=8, cm=%d<=16)", cv, g, heads, cm);
@@ -507,7 +524,7 @@ int pcf_hip_pcf_chain_forward(const float* vi, const int64_t* idx, const float* 
         a.mean[l] = stats + l * 64; a.rstd[l] = stats + (6 + l) * 64;
     }
     a.pe = pe; a.a1 = a1; a.h1 = h1; a.a2 = a2; a.score = score; a.w = w;
-    a.h1_acc = h1_acc; a.a2_acc = a2_acc;
+    a.h1_acc = h1_acc; a.a2_acc = a2_acc; a.ukey = ukey;
     a.part = static_cast<float*>(workspace);
     a.vec_vi = (cv % 4 == 0) && aligned16(vi);
     // passes 3 and 4 restart from the accumulators pass 2 stores, unless the caller wants h1 / a2 themselves
@@ -543,6 +560,32 @@ int pcf_hip_pcf_chain_forward(const float* vi, const int64_t* idx, const float* 
         hipLaunchKernelGGL(pcf_chain_kernel<4>, dim3(chain_grid(E)), dim3(BLOCK), 0, s, a);
     }
     return check_launch("pcf_chain final pass");
+}
+
+int pcf_hip_pcf_chain_forward(const float* vi, const int64_t* idx, const float* u, long long E, long long rows_per_batch,
+                              int N, int K, int cv, int g, int heads, int cm, const float* const* W, const float* const* b,
+                              const float* const* gamma, const float* const* beta, float* const* running_mean,
+                              float* const* running_var, float eps, float momentum, int batch_stats, float* stats,
+                              float* pe, float* a1, float* h1, float* a2, float* h1_acc, float* a2_acc, float* score,
+                              float* w, void* workspace, size_t workspace_bytes, void* stream) {
+    return chain_forward_impl(nullptr, vi, idx, u, E, rows_per_batch, N, K, cv, g, heads, cm, W, b, gamma, beta, running_mean,
+                              running_var, eps, momentum, batch_stats, stats, pe, a1, h1, a2, h1_acc, a2_acc, score, w, workspace,
+                              workspace_bytes, stream);
+}
+
+// Strided layers: the same graph with key = maximum of the query over the neighbourhood (layers.py:372-375).  ukey
+// [E / K, 8] = Wa . max_k guidance_x[idx[n, k]] per centre (K >= 2); everything else as pcf_hip_pcf_chain_forward.
+int pcf_hip_pcf_chain_forward_maxkey(const float* ukey, const float* vi, const int64_t* idx, const float* u, long long E,
+                                     long long rows_per_batch, int N, int K, int cv, int g, int heads, int cm,
+                                     const float* const* W, const float* const* b, const float* const* gamma,
+                                     const float* const* beta, float* const* running_mean, float* const* running_var,
+                                     float eps, float momentum, int batch_stats, float* stats, float* pe, float* a1, float* h1,
+                                     float* a2, float* h1_acc, float* a2_acc, float* score, float* w, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+    if (!ukey) return pcf::fail(PCF_E_BADARG, "pcf_chain_forward_maxkey: ukey is null");
+    return chain_forward_impl(ukey, vi, idx, u, E, rows_per_batch, N, K, cv, g, heads, cm, W, b, gamma, beta, running_mean,
+                              running_var, eps, momentum, batch_stats, stats, pe, a1, h1, a2, h1_acc, a2_acc, score, w, workspace,
+                              workspace_bytes, stream);
 }
 
 // WeightNet alone.  Layer order w1, w2, w3; stats [12][64] laid out as for the full chain (mean of layer l at

@@ -60,6 +60,7 @@ struct ChainBwdArgs {
     float* ga2;                 // [E, 8] da2 * [a2 > 0]
     float* part_top;            // [blocks][2][256] dW tiles of g2 / w3 from pass 2
     float* du;                  // [B*N, 8], zeroed by the host; float atomics
+    float* dukey;               // strided (f.ukey != null): [centres, 8] gradient of ukey = - sum over the neighbourhood of dz(g1)
     int wn_only;                // WeightNet alone: every workgroup runs that branch (and accumulates the VI' moments)
     float* part;                // [blocks][NDW][256] dW / moment tiles of pass 3
     float* part_sums;           // [blocks][96] per-channel sums of the running pass
@@ -260,16 +261,31 @@ __device__ __forceinline__ void guidance_branch(const ChainBwdArgs& a, const flo
         const f32x4 y_pe1 = relu4(pre_of(ac_pe1, cf[S_PE1], g));
         f32x4 dq = bn_dz(g_h1, ac_h1, cf[S_G1], g);
         // z[k] = q[k] - q[key] + b  =>  dq[k] = dz[k] - [k is the key] * (sum over the neighbourhood)
+        f32x4 tot4;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float tot = dq[r];
             for (int off = 1; off < f.K; off <<= 1) tot += __shfl_xor(tot, off, WAVE);
-            if (first) dq[r] -= tot;
+            tot4[r] = tot;
+            if (first && !f.ukey) dq[r] -= tot;
+        }
+        // strided: key = max over the neighbourhood.  z[k] = Wb (pe[k] - pemax) + u[idx k] - ukey + b: the gathered half's key
+        // gradient leaves as dukey, the positional half's goes to the FIRST edge attaining the maximum of each channel
+        f32x4 pm0 = zero4, pm1 = zero4, kf0 = zero4, kf1 = zero4;
+        if (f.ukey) {
+            if (first && g < 2) st4(a.dukey + (size_t)((t * 16 + p) / f.K) * CH + 4 * g, make_float4(-tot4[0], -tot4[1], -tot4[2], -tot4[3]));
+            pm0 = nbr_max(y_pe0, f.K); pm1 = nbr_max(y_pe1, f.K);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float c0 = y_pe0[r] == pm0[r] ? (float)p : 16.f, c1 = y_pe1[r] == pm1[r] ? (float)p : 16.f;
+                kf0[r] = nbr_min(c0, f.K) == (float)p ? 1.f : 0.f;
+                kf1[r] = nbr_min(c1, f.K) == (float)p ? 1.f : 0.f;
+            }
         }
         {
             put_tile(tb + 0 * 16 * TT, dq, p, g);
-            put_tile(tb + 1 * 16 * TT, y_pe0, p, g);
-            put_tile(tb + 2 * 16 * TT, y_pe1, p, g);
+            put_tile(tb + 1 * 16 * TT, y_pe0 - pm0, p, g);
+            put_tile(tb + 2 * 16 * TT, y_pe1 - pm1, p, g);
             // gradient of the gathered term: consecutive lanes cover the 8 consecutive channels of one row of du
             if (g == 0) gi[p] = (int)j_cur;
             for (int e = lane; e < 16 * CH; e += WAVE) {
@@ -280,8 +296,13 @@ __device__ __forceinline__ void guidance_branch(const ChainBwdArgs& a, const flo
             accw[2] = outer(tb + 0 * 16 * TT, tb + 1 * 16 * TT, p, g, accw[2]);
             accw[3] = outer(tb + 0 * 16 * TT, tb + 2 * 16 * TT, p, g, accw[3]);
         }
-        const f32x4 g_pe0 = mask_pos(mm(wl, 10, lane, dq, zero4), y_pe0);
-        const f32x4 g_pe1 = mask_pos(mm(wl, 11, lane, dq, zero4), y_pe1);
+        f32x4 d_pe0 = mm(wl, 10, lane, dq, zero4), d_pe1 = mm(wl, 11, lane, dq, zero4);
+        if (f.ukey) {
+            d_pe0 -= kf0 * mm(wl, 10, lane, tot4, zero4);
+            d_pe1 -= kf1 * mm(wl, 11, lane, tot4, zero4);
+        }
+        const f32x4 g_pe0 = mask_pos(d_pe0, y_pe0);
+        const f32x4 g_pe1 = mask_pos(d_pe1, y_pe1);
         s1[0] += g_pe0; s2[0] += g_pe0 * ac_pe0;
         s1[1] += g_pe1; s2[1] += g_pe1 * ac_pe1;
         {
@@ -904,7 +925,7 @@ static bool chain_bwd_lds_transposes() {
     return v == 1;
 }
 
-static int chain_backward_impl(bool wn_only, const float* vi, const int64_t* idx, const float* h1_acc, const float* a2_acc,
+static int chain_backward_impl(const float* ukey, float* dukey, bool wn_only, const float* vi, const int64_t* idx, const float* h1_acc, const float* a2_acc,
                                const float* dscore, const float* dw, long long E, long long rows_per_batch, int N, int K, int cv, int g, int heads, int cm,
                                const float* const* W, const float* const* b, const float* const* gamma,
                                const float* const* beta, const float* stats, float* du, float* const* dW, float* const* db,
@@ -912,6 +933,8 @@ static int chain_backward_impl(bool wn_only, const float* vi, const int64_t* idx
                                void* stream) {
     using namespace pcf;
     PCF_REQUIRE(E >= 0 && rows_per_batch > 0 && N >= 0, "pcf_chain_backward: bad sizes");
+    if (ukey && (K < 2 || !dukey || !aligned16(dukey)))
+        return fail(PCF_E_UNSUPPORTED, "pcf_chain_backward (maximum key): K >= 2 and dukey a 16-byte aligned [E / K, 8] buffer");
     if (cv < 1 || cv > CV || cm < 1 || cm > CMX || (!wn_only && (g < 1 || g > CG || heads < 1 || heads > CHD)))
         return fail(PCF_E_UNSUPPORTED, "pcf_chain_backward: widths outside the fused kernel (cv=%d<=12, g=%d<=32, heads=%d<=8, cm=%d<=16)", cv, g, heads, cm);
     if (E % 16 != 0 || (!wn_only && (K < 1 || K > 16 || (K & (K - 1)) != 0 || E % rows_per_batch != 0 || rows_per_batch < 16)))
@@ -958,6 +981,7 @@ static int chain_backward_impl(bool wn_only, const float* vi, const int64_t* idx
         a.gmean[l] = means + l * 64; a.gxmean[l] = means + (6 + l) * 64;
     }
     a.dscore = dscore; a.dw = dw; a.du = du; a.h1_acc = h1_acc; a.a2_acc = a2_acc; a.wn_only = wn_only ? 1 : 0;
+    a.f.ukey = ukey; a.dukey = dukey;
     // both branches need at least one workgroup; a multiple of 8 keeps the 5 : 3 split exact
     const int grid = std::max(8, (chain_grid(E) + 7) / 8 * 8);
     // pass 1 mostly streams (2048 workgroups keep more bytes in flight: 57 -> 49 us); passes 2-3 stay at 1024
@@ -981,7 +1005,7 @@ static int chain_backward_impl(bool wn_only, const float* vi, const int64_t* idx
         hipLaunchKernelGGL(chain_bwd_finalize_kernel, dim3(12), dim3(1024), 0, s, fa);
         if (int e = check_launch("pcf_chain_backward finalize")) return e;
     }
-    if (chain_bwd_lds_transposes()) {
+    if (chain_bwd_lds_transposes() || ukey) {          // the maximum-key form exists with the LDS transposes only
         hipLaunchKernelGGL((pcf_chain_bwd_kernel<3, false>), dim3(grid), dim3(BLOCK), 0, s, a, grid / 8);
         if (int e = check_launch("pcf_chain_bwd_kernel<3> (LDS transposes)")) return e;
     } else {
@@ -1023,8 +1047,22 @@ int pcf_hip_pcf_chain_backward(const float* vi, const int64_t* idx, const float*
                                const float* const* gamma, const float* const* beta, const float* stats, float* du,
                                float* const* dW, float* const* db, float* const* dgamma, float* const* dbeta,
                                void* workspace, size_t workspace_bytes, void* stream) {
-    return chain_backward_impl(false, vi, idx, h1_acc, a2_acc, dscore, dw, E, rows_per_batch, N, K, cv, g, heads, cm, W, b,
+    return chain_backward_impl(nullptr, nullptr, false, vi, idx, h1_acc, a2_acc, dscore, dw, E, rows_per_batch, N, K, cv, g, heads, cm, W, b,
                                gamma, beta, stats, du, dW, db, dgamma, dbeta, workspace, workspace_bytes, stream);
+}
+
+// adjoint of pcf_hip_pcf_chain_forward_maxkey: additionally dukey [E / K, 8] (ukey itself is not read: a non-null pointer
+// selects the form)
+int pcf_hip_pcf_chain_backward_maxkey(const float* ukey, float* dukey, const float* vi, const int64_t* idx, const float* h1_acc,
+                                      const float* a2_acc, const float* dscore, const float* dw, long long E,
+                                      long long rows_per_batch, int N, int K, int cv, int g, int heads, int cm,
+                                      const float* const* W, const float* const* b, const float* const* gamma,
+                                      const float* const* beta, const float* stats, float* du, float* const* dW,
+                                      float* const* db, float* const* dgamma, float* const* dbeta, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+    if (!ukey || !dukey) return pcf::fail(PCF_E_BADARG, "pcf_chain_backward_maxkey: ukey / dukey is null");
+    return chain_backward_impl(ukey, dukey, false, vi, idx, h1_acc, a2_acc, dscore, dw, E, rows_per_batch, N, K, cv, g, heads, cm, W,
+                               b, gamma, beta, stats, du, dW, db, dgamma, dbeta, workspace, workspace_bytes, stream);
 }
 
 // WeightNet alone (adjoint of pcf_hip_weightnet_chain_forward): layer order w1, w2, w3 in every array.
@@ -1043,7 +1081,7 @@ int pcf_hip_weightnet_chain_backward(const float* x, const float* a2_acc, const 
     float* db6[6] = {nullptr, nullptr, nullptr, db[0], db[1], db[2]};
     float* dg6[6] = {nullptr, nullptr, nullptr, dgamma[0], dgamma[1], dgamma[2]};
     float* dbe6[6] = {nullptr, nullptr, nullptr, dbeta[0], dbeta[1], dbeta[2]};
-    return chain_backward_impl(true, x, nullptr, nullptr, a2_acc, nullptr, dw, E, E > 0 ? E : 1, 0, 1, cin, 0, 0, cm, W6, b6, g6,
+    return chain_backward_impl(nullptr, nullptr, true, x, nullptr, nullptr, a2_acc, nullptr, dw, E, E > 0 ? E : 1, 0, 1, cin, 0, 0, cm, W6, b6, g6,
                                be6, stats, nullptr, dW6, db6, dg6, dbe6, workspace, workspace_bytes, stream);
 }
 

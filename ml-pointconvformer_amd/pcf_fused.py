@@ -624,6 +624,12 @@ _chain_fwd = _sig('pcf_hip_pcf_chain_forward',
 _chain_bwd_ws = getattr(_lib, 'pcf_hip_pcf_chain_backward_workspace_bytes')
 _chain_bwd_ws.argtypes = [_LL]
 _chain_bwd_ws.restype = _Z
+_chain_fwd_mk = _sig('pcf_hip_pcf_chain_forward_maxkey',
+                     [_P, _P, _P, _P, _LL, _LL, _I, _I, _I, _I, _I, _I, _PP, _PP, _PP, _PP, _PP, _PP, _F, _F, _I, _P,
+                      _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P])
+_chain_bwd_mk = _sig('pcf_hip_pcf_chain_backward_maxkey',
+                     [_P, _P, _P, _P, _P, _P, _P, _P, _LL, _LL, _I, _I, _I, _I, _I, _I, _PP, _PP, _PP, _PP, _P, _P, _PP, _PP, _PP,
+                      _PP, _P, _Z, _P])
 _chain_bwd = _sig('pcf_hip_pcf_chain_backward',
                   [_P, _P, _P, _P, _P, _P, _LL, _LL, _I, _I, _I, _I, _I, _I, _PP, _PP, _PP, _PP, _P, _P, _PP, _PP, _PP, _PP,
                    _P, _Z, _P])
@@ -660,10 +666,11 @@ class _PCFChain(torch.autograd.Function):
 
     Tensor inputs: vi [B,M,K,cv], u [B,N,8], fx [B,N,Ci], then (W, b, gamma, beta) of the six layers in the
     order mlp_conv, g1 (positional half of the weight), g2, w1, w2, w3.  `bns` are the six BatchNorm1d modules
-    (running statistics are updated in place in training)."""
+    (running statistics are updated in place in training).  ukey [B,M,8] (or None): strided layers, key = maximum of the
+    query over the neighbourhood -- the gathered half of that key, Wa . max_k guidance_x[idx], formed by the caller."""
 
     @staticmethod
-    def forward(ctx, idx, bns, training, fused_backward, vi, u, fx, *params):
+    def forward(ctx, idx, bns, training, fused_backward, ukey, vi, u, fx, *params):
         dev = vi.device
         B, M, K, cv = vi.shape
         N = u.shape[1]
@@ -695,21 +702,26 @@ class _PCFChain(torch.autograd.Function):
         rm = _ptr_array([bn.running_mean for bn in bns]) if training else None
         rv = _ptr_array([bn.running_var for bn in bns]) if training else None
         mom = bns[0].momentum               # same_bn_hyperparameters(): one eps / momentum for the chain, not None
+        if ukey is not None:
+            ukey = ukey.contiguous()
         with _guard(dev):
-            _call(_chain_fwd, _ptr(vi), _ptr(idx), _ptr(u), E, M * K, N, K, cv, g, heads, cm, _ptr_array(Ws), _ptr_array(bs),
-                  _ptr_array(gammas), _ptr_array(betas), rm, rv, float(bns[0].eps), float(mom), 1 if training else 0,
-                  stats.data_ptr(), _ptr(pe), _ptr(a1), _ptr(h1), _ptr(a2), _ptr(h1_acc), _ptr(a2_acc), _ptr(score), _ptr(w),
-                  ws.data_ptr(), nbytes,
-                  _stream(dev))
+            tail = (_ptr(vi), _ptr(idx), _ptr(u), E, M * K, N, K, cv, g, heads, cm, _ptr_array(Ws), _ptr_array(bs),
+                    _ptr_array(gammas), _ptr_array(betas), rm, rv, float(bns[0].eps), float(mom), 1 if training else 0,
+                    stats.data_ptr(), _ptr(pe), _ptr(a1), _ptr(h1), _ptr(a2), _ptr(h1_acc), _ptr(a2_acc), _ptr(score), _ptr(w),
+                    ws.data_ptr(), nbytes, _stream(dev))
+            if ukey is None:
+                _call(_chain_fwd, *tail)
+            else:
+                _call(_chain_fwd_mk, _ptr(ukey), *tail)
         agg = pcf_cuda.pcf_forward(fx, idx, score, w)
-        ctx.save_for_backward(idx, vi, u, fx, stats, pe, a1, h1, a2, h1_acc, a2_acc, score, w, *keep)
+        ctx.save_for_backward(idx, vi, u, fx, stats, pe, a1, h1, a2, h1_acc, a2_acc, score, w, ukey, *keep)
         ctx.training = bool(training)
         ctx.fused_backward = bool(fused_backward)
         return agg
 
     @staticmethod
     def backward(ctx, dagg):
-        idx, vi, u, fx, stats, pe, a1, h1, a2, h1_acc, a2_acc, score, w, *keep = ctx.saved_tensors
+        idx, vi, u, fx, stats, pe, a1, h1, a2, h1_acc, a2_acc, score, w, ukey, *keep = ctx.saved_tensors
         if not ctx.training:
             raise RuntimeError('pcf_chain: backward needs the training-mode forward (batch statistics)')
         Ws, bs, gammas, betas = keep[0::4], keep[1::4], keep[2::4], keep[3::4]
@@ -724,12 +736,20 @@ class _PCFChain(torch.autograd.Function):
                 grads = [torch.empty_like(t) for t in keep]
                 nbytes = _chain_bwd_ws(B * M * K)
                 ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-                _call(_chain_bwd, _ptr(vi), _ptr(idx), _ptr(h1_acc), _ptr(a2_acc), _ptr(dscore), _ptr(dw), B * M * K, M * K,
-                      u.shape[1], K, cv,
-                      Ws[0].shape[0], Ws[2].shape[0], Ws[5].shape[0], _ptr_array(Ws), _ptr_array(bs), _ptr_array(gammas),
-                      _ptr_array(betas), stats.data_ptr(), _ptr(du), _ptr_array(grads[0::4]), _ptr_array(grads[1::4]),
-                      _ptr_array(grads[2::4]), _ptr_array(grads[3::4]), ws.data_ptr(), nbytes, _stream(dev))
-            return (None, None, None, None, None, du, dfx, *grads)
+                tail = (_ptr(vi), _ptr(idx), _ptr(h1_acc), _ptr(a2_acc), _ptr(dscore), _ptr(dw), B * M * K, M * K,
+                        u.shape[1], K, cv,
+                        Ws[0].shape[0], Ws[2].shape[0], Ws[5].shape[0], _ptr_array(Ws), _ptr_array(bs), _ptr_array(gammas),
+                        _ptr_array(betas), stats.data_ptr(), _ptr(du), _ptr_array(grads[0::4]), _ptr_array(grads[1::4]),
+                        _ptr_array(grads[2::4]), _ptr_array(grads[3::4]), ws.data_ptr(), nbytes, _stream(dev))
+                dukey = None
+                if ukey is None:
+                    _call(_chain_bwd, *tail)
+                else:
+                    dukey = torch.empty_like(ukey)
+                    _call(_chain_bwd_mk, _ptr(ukey), _ptr(dukey), *tail)
+            return (None, None, None, None, dukey, None, du, dfx, *grads)
+        if ukey is not None:
+            raise RuntimeError('pcf_chain: the maximum-key form has the fused backward only')
         with _guard(dagg.device):
             dfx, dscore, dw = pcf_cuda.pcf_backward(dagg.contiguous(), fx, idx, score, w)
             L = {}
@@ -743,7 +763,7 @@ class _PCFChain(torch.autograd.Function):
         grads = []
         for l in range(6):
             grads.extend(L[l])
-        return (None, None, None, None, None, du, dfx, *grads)
+        return (None, None, None, None, None, None, du, dfx, *grads)
 
 
 _wn_fwd = _sig('pcf_hip_weightnet_chain_forward',
@@ -846,7 +866,7 @@ def pcf_chain_supported(cv, g, heads, cm, K, hidden_ok, n_edges, edges_per_batch
         and 1 <= K <= 16 and (K & (K - 1)) == 0 and n_edges % 16 == 0 and edges_per_batch >= 16
 
 
-def pcf_chain(vi, idx, u, fx, layers, training, fused_backward=True, g1_positional_weight=None):
+def pcf_chain(vi, idx, u, fx, layers, training, fused_backward=True, g1_positional_weight=None, ukey=None):
     """layers: six (nn.Linear, nn.BatchNorm1d) pairs in the order mlp_conv, g1, g2, w1, w2, w3; the g1 weight is
     split here (its gathered half already went into `u`).  fused_backward: adjoint through the three-pass
     recompute kernel (csrc/edge_chain_bwd.hip); False keeps the activations and goes layer by layer."""
@@ -859,7 +879,7 @@ def pcf_chain(vi, idx, u, fx, layers, training, fused_backward=True, g1_position
         if l == 1:      # positional half of the first guidance layer (the gathered half already went into `u`)
             W = g1_positional_weight if g1_positional_weight is not None else lin.weight[:, lin.weight.shape[1] - G:]
         params += [W, lin.bias, bn.weight, bn.bias]
-    return _PCFChain.apply(idx, [bn for _, bn in layers], training, fused_backward, vi, u, fx, *params)
+    return _PCFChain.apply(idx, [bn for _, bn in layers], training, fused_backward, ukey, vi, u, fx, *params)
 
 
 # --------------------------------------------------------------------------------------------------

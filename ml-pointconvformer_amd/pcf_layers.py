@@ -440,15 +440,30 @@ class PCFLayer(pcf_fused.CounterScope):
         nei_inds = nei_inds.contiguous()
         _, wn_in = _edge_geometry(self.cfg.USE_VI is True, dense_xyz, dense_xyz_norm, nei_inds, ctr_xyz, ctr_norm,
                                   vi_features, want_rel=False)
-        chain = self._chain_layers(wn_in, nei_inds) if not strided else None
+        chain = self._chain_layers(wn_in, nei_inds)
+        if strided and chain is not None and (nei_inds.shape[2] < 2 or getattr(self.cfg, 'EDGE_CHAIN_LAYERWISE_BACKWARD', False)):
+            chain = None            # the maximum-key form of the chain: K >= 2, fused backward only
         fused_points = self.training and not getattr(self.cfg, 'NO_POINT_CHAIN', False)
         if chain is not None:
-            # self neighbourhoods, BatchNorm everywhere: the whole edge graph in four fused passes forward, three backward
+            # BatchNorm everywhere: the whole edge graph in four fused passes forward, three backward (self neighbourhoods:
+            # key = neighbour 0; strided: key = maximum over the neighbourhood)
             g1 = self.guidance_weight.mlp[0].c
             G = self.guidance_unary.out_dim
             Wa, Wb = pcf_fused.split_columns(g1.weight, G)      # gathered half | positional half
             u1 = self.unary1 if isinstance(self.unary1, UnaryBlock) else None
-            if fused_points and pcf_fused.point_chain_ok(self.guidance_unary.mlp.bn, *([u1.mlp.bn] if u1 is not None else [])):
+            ukey = None
+            if strided:
+                # key = max of the query over the neighbourhood (layers.py:372-375): its gathered half per centre, Wa . max_k
+                # guidance_x[idx]; the positional half is taken inside the chain kernels
+                feats_x = self.unary1(dense_feats)
+                guidance_x = self.guidance_unary(feats_x).contiguous()
+                if self._zero8.device != Wa.device:
+                    self._zero8 = self._zero8.to(Wa.device)
+                zero = self._zero8[:g1.out_features]
+                u = pcf_fused.linear_bn_act(guidance_x, Wa, zero, None, pcf_fused.ACT_NONE, self.training)
+                ukey = pcf_fused.linear_bn_act(pcf_fused.gather_max(guidance_x, nei_inds), Wa, zero, None, pcf_fused.ACT_NONE,
+                                               self.training)
+            elif fused_points and pcf_fused.point_chain_ok(self.guidance_unary.mlp.bn, *([u1.mlp.bn] if u1 is not None else [])):
                 # unary1 -> guidance_unary -> u in three launches (BatchNorms folded into the contractions)
                 feats_x, u = pcf_fused.point_head(dense_feats, u1, self.guidance_unary, Wa)
             else:
@@ -459,7 +474,7 @@ class PCFLayer(pcf_fused.CounterScope):
                 u = pcf_fused.linear_bn_act(guidance_x, Wa, self._zero8[:g1.out_features], None, pcf_fused.ACT_NONE, self.training)
             agg = pcf_fused.pcf_chain(wn_in.contiguous(), nei_inds, u, feats_x.contiguous(), chain, self.training,
                                       fused_backward=not getattr(self.cfg, 'EDGE_CHAIN_LAYERWISE_BACKWARD', False),
-                                      g1_positional_weight=Wb)
+                                      g1_positional_weight=Wb, ukey=ukey)
         else:
             feats_x = self.unary1(dense_feats)
             guidance_x = self.guidance_unary(feats_x)

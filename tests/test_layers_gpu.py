@@ -739,6 +739,50 @@ def test_pe_chain_against_float64_and_layer_at_a_time(device, rows, hidden, cout
     assert float(pcf_fused._tickets(device).abs().sum()) == 0.0
 
 
+@pytest.mark.parametrize('K,n_dense,n_out', [(16, 3000, 700), (4, 1000, 400), (8, 2000, 512)])
+def test_strided_pcf_layer_chain_against_layer_by_layer(device, K, n_dense, n_out):
+    """Strided PCFLayer (key = maximum of the query over the neighbourhood, layers.py:372-375) through the fused edge chain
+    (maximum-key form: the gathered half of the key per centre, the positional half and its arg-max inside the kernels) against
+    the same layer with every edge layer through its own kernels (`NO_EDGE_CHAIN`, itself held to the reference by the
+    pcf_strided golden).  A third of the neighbour lists repeat entries, so positional maxima are attained by several edges:
+    the gradient must go to the first one, as torch.max does.  Output, feature gradient and every parameter gradient."""
+    import pcf_cuda
+    import pcf_layers
+    g = torch.Generator().manual_seed(K)
+    xyz = torch.rand(1, n_dense, 3, generator=g)
+    nrm = torch.nn.functional.normalize(torch.randn(1, n_dense, 3, generator=g), dim=-1)
+    ctr = torch.randperm(n_dense, generator=g)[:n_out]
+    sxyz, snrm = xyz[:, ctr], nrm[:, ctr]
+    idx = torch.randint(0, n_dense, (1, n_out, K), generator=g)
+    idx[:, ::3, 1::2] = idx[:, ::3, 0:-1:2]                  # repeated neighbours: ties of the maximum
+    feats = torch.randn(1, n_dense, 64, generator=g)
+    up = torch.randn(1, n_out, 128, generator=g)
+    res = {}
+    for mode in ('fused', 'off'):
+        torch.manual_seed(11)
+        layer = pcf_layers.PCFLayer(64, 128, cfg(**CHAIN_MODES[mode]), weightnet=[12, 16], num_heads=8,
+                                    guidance_feat_len=32).to(device).train()
+        with torch.no_grad():
+            for m in layer.modules():
+                if isinstance(m, torch.nn.BatchNorm1d):
+                    m.weight.uniform_(0.5, 1.5)
+                    m.bias.uniform_(-0.3, 0.3)
+        x = feats.clone().to(device).requires_grad_(True)
+        pcf_cuda.launch_log(True)
+        out, _ = layer(xyz.to(device), x, idx.to(device), nrm.to(device), sxyz.to(device), snrm.to(device))
+        out.backward(up.to(device))
+        names = pcf_cuda.read_launch_log()
+        pcf_cuda.launch_log(False)
+        assert any('guidance_diff' in n for n in names) == (mode == 'off'), names      # the explicit query - max(query) kernel
+        res[mode] = dict(out=out.detach(), x=x.grad, **{n: p.grad for n, p in layer.named_parameters()},
+                         **{'buf.' + n: b.clone().float() for n, b in layer.named_buffers()})
+    top = max(float(t.abs().max()) for k, t in res['off'].items() if k not in ('out', 'x') and not k.startswith('buf.'))
+    for k, v in res['fused'].items():
+        ref = res['off'][k]
+        scale = float(ref.abs().max()) + 1e-12
+        torch.testing.assert_close(v, ref, rtol=1e-3, atol=1e-3 * scale + 2e-5 * top, msg=lambda m, n=k: f'{n}: {m}')
+
+
 def test_pe_chain_is_repeatable_with_many_short_workgroups(device):
     """Regression: 51 973 x 16 edges = 2048 workgroups of six tiles per wave.  The hand-over of the per-workgroup partial sums
     to the workgroup that finishes last used "atomic store, workgroup-scope fence, ticket"; that fence compiles to no
