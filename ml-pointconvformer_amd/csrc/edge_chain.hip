@@ -1,4 +1,5 @@
-// Fused forward of the per-edge graph of a PCFLayer (self neighbourhoods) on gfx950.
+// Fused forward of the per-edge graph of a PCFLayer on gfx950 (self neighbourhoods: key = neighbour 0; strided layers:
+// key = maximum of the query over the neighbourhood, ChainArgs::ukey).
 //
 //        VI[e] (<=12) --mlp_conv--> pe (<=32) --+                           guidance branch
 //                                               +-- Wb.pe + u[idx[e]] - (same for the key edge) + b
