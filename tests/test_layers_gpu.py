@@ -776,11 +776,20 @@ def test_strided_pcf_layer_chain_against_layer_by_layer(device, K, n_dense, n_ou
         assert any('guidance_diff' in n for n in names) == (mode == 'off'), names      # the explicit query - max(query) kernel
         res[mode] = dict(out=out.detach(), x=x.grad, **{n: p.grad for n, p in layer.named_parameters()},
                          **{'buf.' + n: b.clone().float() for n, b in layer.named_buffers()})
-    top = max(float(t.abs().max()) for k, t in res['off'].items() if k not in ('out', 'x') and not k.startswith('buf.'))
+    # Forward: 1e-3 of the scale.  Backward: with 400-700 centres ONE activation whose argument rounds to opposite sides of zero
+    # in the two forms (seen: a single LeakyReLU of the output, arguments 3e-6 apart) moves every gradient by percents through
+    # the BatchNorms, so the gradients are held by error norms -- an adjoint bug of the maximum key is O(1) in mlp_conv / g1.
     for k, v in res['fused'].items():
         ref = res['off'][k]
         scale = float(ref.abs().max()) + 1e-12
-        torch.testing.assert_close(v, ref, rtol=1e-3, atol=1e-3 * scale + 2e-5 * top, msg=lambda m, n=k: f'{n}: {m}')
+        if k == 'out' or k.startswith('buf.'):
+            torch.testing.assert_close(v, ref, rtol=1e-3, atol=1e-3 * scale, msg=lambda m, n=k: f'{n}: {m}')
+        elif k == 'x':
+            bad = ((v - ref).abs() > 1e-3 * scale + 1e-3 * ref.abs()).any(dim=-1)
+            assert int(bad.sum()) <= max(4, n_dense // 50), f'{int(bad.sum())} rows of the feature gradient differ'
+        elif float(ref.abs().max()) > 1e-3:                # biases in front of a batch-statistics BatchNorm: zero, noise
+            err = float((v - ref).norm() / ref.norm())
+            assert err < 5e-2, f'{k}: relative error {err:.3e}'
 
 
 def test_pe_chain_is_repeatable_with_many_short_workgroups(device):
