@@ -1094,6 +1094,33 @@ class _PointTail(torch.autograd.Function):
         return (None, dagg, dsc, dW3, db3, dg3, dbe3, dW4, db4, dg4, dbe4)
 
 
+# The contraction kernels with fused statistics (csrc/fused_linear.hip) carry ~10 us of ticketed hand-over per launch: at
+# parity with the layer-by-layer kernels on 80k rows (435 vs 450 us per PCFLayer step), slower on the smaller tensors of the
+# models' levels -- whole training iterations with them everywhere / from 32768 rows / never: 10cm-lite 21.58 / 21.39 / 21.15 ms,
+# PCF_Normal 26.99 / 26.66 / 26.32 ms, 5cm 26.65 / 26.55 / 26.34 ms.  So below this row count only the row chains of
+# csrc/point_chain.hip (whole layer chains per pass, at the widths they are instantiated for) replace the layer-by-layer path.
+FLIN_CHAIN_MIN_ROWS = 65536
+
+
+def head_chain_pays(x, unary1, guidance_unary, wa_rows=8, force=False):
+    rows = x.numel() // max(1, x.shape[-1])
+    if force:
+        return True
+    if unary1 is not None and wa_rows == 8 and rows > 0 and \
+            point_head_chain_supported(unary1.mlp.c.in_features, unary1.mlp.c.out_features, guidance_unary.mlp.c.out_features):
+        return True
+    return rows >= FLIN_CHAIN_MIN_ROWS
+
+
+def tail_chain_pays(agg, linear, unary2, force=False):
+    rows = agg.numel() // max(1, agg.shape[-1])
+    if force:
+        return True
+    if rows > 0 and point_tail_chain_supported(linear.c.in_features, linear.c.out_features, unary2.mlp.c.out_features):
+        return True
+    return rows >= FLIN_CHAIN_MIN_ROWS
+
+
 def point_chain_ok(*bns):
     """The fused point-level chains apply in training mode to plain (rank-local) BatchNorms with the exponential
     running-statistics update."""

@@ -444,6 +444,7 @@ class PCFLayer(pcf_fused.CounterScope):
         if strided and chain is not None and (nei_inds.shape[2] < 2 or getattr(self.cfg, 'EDGE_CHAIN_LAYERWISE_BACKWARD', False)):
             chain = None            # the maximum-key form of the chain: K >= 2, fused backward only
         fused_points = self.training and not getattr(self.cfg, 'NO_POINT_CHAIN', False)
+        force_flin = bool(getattr(self.cfg, 'FLIN_POINT_CHAINS', False))     # fused contraction chains whatever the row count
         if chain is not None:
             # BatchNorm everywhere: the whole edge graph in four fused passes forward, three backward (self neighbourhoods:
             # key = neighbour 0; strided: key = maximum over the neighbourhood)
@@ -463,7 +464,8 @@ class PCFLayer(pcf_fused.CounterScope):
                 u = pcf_fused.linear_bn_act(guidance_x, Wa, zero, None, pcf_fused.ACT_NONE, self.training)
                 ukey = pcf_fused.linear_bn_act(pcf_fused.gather_max(guidance_x, nei_inds), Wa, zero, None, pcf_fused.ACT_NONE,
                                                self.training)
-            elif fused_points and pcf_fused.point_chain_ok(self.guidance_unary.mlp.bn, *([u1.mlp.bn] if u1 is not None else [])):
+            elif fused_points and pcf_fused.head_chain_pays(dense_feats, u1, self.guidance_unary, force=force_flin) \
+                    and pcf_fused.point_chain_ok(self.guidance_unary.mlp.bn, *([u1.mlp.bn] if u1 is not None else [])):
                 # unary1 -> guidance_unary -> u in three launches (BatchNorms folded into the contractions)
                 feats_x, u = pcf_fused.point_head(dense_feats, u1, self.guidance_unary, Wa)
             else:
@@ -500,6 +502,7 @@ class PCFLayer(pcf_fused.CounterScope):
         sparse_feats = pcf_fused.gather_max(dense_feats, nei_inds) if strided else dense_feats
         shortcut = self.unary_shortcut(sparse_feats)
         if fused_points and isinstance(self.linear, Linear_BN) and isinstance(self.dropout, nn.Identity) \
+                and pcf_fused.tail_chain_pays(agg, self.linear, self.unary2, force=force_flin) \
                 and not (isinstance(self.drop_path, DropPath) and self.drop_path.drop_prob > 0.) \
                 and pcf_fused.point_chain_ok(self.linear.bn, self.unary2.mlp.bn):
             # linear + ReLU -> unary2 -> + shortcut -> LeakyReLU in three launches forward, five backward

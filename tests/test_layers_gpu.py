@@ -85,10 +85,11 @@ PCF_ORDER = ['dense_xyz', 'dense_feats', 'nei_inds', 'dense_xyz_norm', 'sparse_x
 
 
 # edge graph: fused forward + fused three-pass backward (default) / fused forward + layer-at-a-time backward /
-# every layer through its own kernels / fused edge graph but the point-level Linear_BN layers one by one (the default
-# folds their BatchNorms into the neighbouring contractions: csrc/fused_linear.hip)
+# every layer through its own kernels / fused edge graph but the point-level Linear_BN layers one by one / the point-level
+# layers as fused contraction chains (csrc/fused_linear.hip) whatever the row count (the default uses them from 65536 rows, the
+# row chains of csrc/point_chain.hip at the BASELINE widths, the layer-by-layer kernels otherwise)
 CHAIN_MODES = {'fused': {}, 'layerwise_bwd': dict(EDGE_CHAIN_LAYERWISE_BACKWARD=True), 'off': dict(NO_EDGE_CHAIN=True),
-               'point_layers_one_by_one': dict(NO_POINT_CHAIN=True)}
+               'point_layers_one_by_one': dict(NO_POINT_CHAIN=True), 'flin_point_chains': dict(FLIN_POINT_CHAINS=True)}
 
 
 @pytest.mark.parametrize('mode', list(CHAIN_MODES))
