@@ -168,6 +168,16 @@ int pcf_hip_adamw_list(int phase, int n, float* const* params, float* const* gra
                        double weight_decay, void* stream);
 int pcf_hip_adamw_finish(const float* partials, int n_partials, float* rec, float max_norm, double beta1, double beta2, void* stream);
 
+/* criterion(pred, target) of the training loop (train_ScanNet_DDP_WarmUP.py:243, :404): nn.CrossEntropyLoss(ignore_index,
+ * label_smoothing), mean over the rows that are not ignored.  Forward: stat[0] = loss, stat[1] = number of valid rows, dlogits =
+ * gradient of the loss sum; backward: dx = dlogits * grad_out / stat[1].  At most 64 classes; deterministic. */
+size_t pcf_hip_cross_entropy_workspace_bytes(long long R);
+int pcf_hip_cross_entropy_forward(const float* logits, const int64_t* target, long long R, int C, long long ignore_index,
+                                  float label_smoothing, float* stat, float* dlogits, void* workspace, size_t workspace_bytes,
+                                  void* stream);
+int pcf_hip_cross_entropy_backward(const float* dlogits, const float* grad_out, const float* stat, long long R, int C, float* dx,
+                                   void* stream);
+
 /* ---- attention arithmetic of the ablation layers ------------------------------------------------
  * softmax_aggregate: PointTransformerLayer.forward, layers.py:519-527.  v [R,K,C], logit [R,K,J] (J divides C: the
  *   share_planes groups) -> sm = softmax over K of logit (saved for the backward), out[r,c] = sum_k v[r,k,c] * sm[r,k,c % J].

@@ -21,6 +21,7 @@ import math
 import torch
 
 import knn_post_dataloader_utils as knn_utils
+import pcf_fused
 
 
 # The model + optimisation keys of the four model YAMLs BASELINE.json names (values restated from
@@ -137,7 +138,11 @@ def training_iteration(model, optimizer, criterion, cfg, batch, edges=None):
     features, pointclouds, target, norms, points_stored = batch
     es, ef, ep, inv = edges if edges is not None else build_edges(cfg, pointclouds, points_stored)
     pred = model(features, pointclouds, es, ef, ep, norms, *inv)
-    loss = criterion(pred.reshape(-1, cfg.num_classes), target)
+    logits = pred.reshape(-1, cfg.num_classes)
+    if pcf_fused.cross_entropy_supported(criterion, logits):          # the same loss, three launches instead of torch's chain
+        loss = pcf_fused.cross_entropy(logits, target, criterion.ignore_index, criterion.label_smoothing)
+    else:
+        loss = criterion(logits, target)
     loss.backward()
     if hasattr(optimizer, 'last_grad_norm'):          # pcf_optim.FusedAdamW: norm, clip and update in one pass
         optimizer.step(max_grad_norm=10)

@@ -131,3 +131,31 @@ def test_fused_adamw_with_clipping_equals_torch(device):
         a.grad = torch.ones_like(a)
     again.step()
     assert float(again.state[mine[0]]['step']) == 7
+
+
+@pytest.mark.parametrize('R,C,smoothing,ignored', [(144157, 20, 0.1, 0.2), (1000, 13, 0.0, 0.0), (257, 64, 0.3, 0.9), (5, 3, 0.0, 0.4)])
+def test_fused_cross_entropy_equals_torch(device, R, C, smoothing, ignored):
+    """pcf_fused.cross_entropy against nn.CrossEntropyLoss(ignore_index, label_smoothing) (train_ScanNet_DDP_WarmUP.py:243,
+    :404): loss and logit gradient (scaled by an upstream factor), rows with the ignore label contribute nothing."""
+    import pcf_fused
+    g = torch.Generator().manual_seed(R + C)
+    logits = (torch.randn(R, C, generator=g) * 3).to(device)
+    target = torch.randint(0, C, (R,), generator=g)
+    target[torch.rand(R, generator=g) < ignored] = -100
+    target[0] = 1                                                # at least one valid row
+    target = target.to(device)
+    crit = torch.nn.CrossEntropyLoss(ignore_index=-100, label_smoothing=smoothing).to(device)
+    a = logits.clone().requires_grad_(True)
+    b = logits.clone().requires_grad_(True)
+    assert pcf_fused.cross_entropy_supported(crit, a)
+    la = pcf_fused.cross_entropy(a, target, -100, smoothing)
+    lb = crit(b, target)
+    (2.5 * la).backward()
+    (2.5 * lb).backward()
+    torch.testing.assert_close(la, lb, rtol=2e-6, atol=1e-6)
+    torch.testing.assert_close(a.grad, b.grad, rtol=1e-5, atol=1e-8)
+    assert float(a.grad[target == -100].abs().sum()) == 0.0
+    again = pcf_fused.cross_entropy(logits, target, -100, smoothing)
+    assert torch.equal(again, la.detach())                       # fixed summation order
+    none_valid = pcf_fused.cross_entropy(logits[:4], torch.full((4,), -100, dtype=torch.int64, device=device), -100, smoothing)
+    assert torch.isnan(none_valid)                               # torch: mean over zero rows
