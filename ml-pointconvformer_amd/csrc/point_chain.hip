@@ -113,6 +113,40 @@ __device__ __forceinline__ bool pass_totals(const f32x4 (&s1)[NT], const f32x4 (
         for (int w = 0; w < NWAVE; ++w) a += wsum[w][v];
         st_agent(part + (size_t)blockIdx.x * NV + v, a);
     }
+    const int v = threadIdx.x % NV, sl = threadIdx.x / NV;
+    if (gridDim.x <= PC_MAXB) {
+        // up to 256 lists: ONE level, the last workgroup reads them all with 16 loads in flight per lane (a second ticket round
+        // costs more than the longer walk)
+        publish();
+        __syncthreads();
+        if (threadIdx.x == 0) s_last = (atomicAdd(ticket, 1) == (int)gridDim.x - 1) ? 1 : 0;
+        __syncthreads();
+        if (!s_last) return false;
+        observe();
+        double a = 0.0;
+        if (sl < SL) {
+            int q = sl;
+            for (; q + 15 * SL < (int)gridDim.x; q += 16 * SL) {
+                float t[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) t[i] = ld_agent(part + (size_t)(q + i * SL) * NV + v);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) a += (double)t[i];
+            }
+            for (; q < (int)gridDim.x; q += SL) a += (double)ld_agent(part + (size_t)q * NV + v);
+        }
+        red[threadIdx.x] = a;
+        __syncthreads();
+        if (threadIdx.x < NV) {
+            double b = 0.0;
+#pragma unroll
+            for (int s = 0; s < SL; ++s) b += red[s * NV + threadIdx.x];
+            tot[threadIdx.x] = b;
+        }
+        if (threadIdx.x == 0) st_agent(ticket, 0);
+        __syncthreads();
+        return true;
+    }
     const int grp = blockIdx.x / PC_GROUP, ngroups = ((int)gridDim.x + PC_GROUP - 1) / PC_GROUP;
     const int g0 = grp * PC_GROUP, gsize = min(PC_GROUP, (int)gridDim.x - g0);
     publish();
@@ -121,7 +155,6 @@ __device__ __forceinline__ bool pass_totals(const f32x4 (&s1)[NT], const f32x4 (
     __syncthreads();
     if (!s_last) return false;
     observe();
-    const int v = threadIdx.x % NV, sl = threadIdx.x / NV;
     {
         float acc[PC_GROUP / SL + 1];
         int n = 0;
