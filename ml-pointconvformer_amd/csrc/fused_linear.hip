@@ -165,8 +165,11 @@ __device__ __forceinline__ bool column_totals(float s1, float s2, int n0, int N,
         float a = 0.f;
 #pragma unroll
         for (int wm = 0; wm < WM; ++wm) a += csum[wm * WN + wn][which][c];
-        if (col < N) st_agent(part + ((size_t)blockIdx.y * 2 + which) * N + col, a);
+        if (!ticket) {                               // a separate launch combines the lists (flin_finish_kernel)
+            if (col < N) part[((size_t)blockIdx.y * 2 + which) * N + col] = a;
+        } else if (col < N) st_agent(part + ((size_t)blockIdx.y * 2 + which) * N + col, a);
     }
+    if (!ticket) return false;
     const int groups = ((int)gridDim.y + FL_GROUP - 1) / FL_GROUP, grp = blockIdx.y / FL_GROUP;
     const int gsize = min(FL_GROUP, (int)gridDim.y - grp * FL_GROUP);
     int* t1 = ticket + blockIdx.x * (FL_MAXG + 1);
@@ -756,9 +759,15 @@ __global__ __launch_bounds__(BLOCK) void bn_bwd_stats_kernel(const TopArgs a) {
     __syncthreads();
     if (ty == 0 && c < a.C) {
         for (int y = 1; y < TY; ++y) { sa += s1[y * TX + tx]; sb += s2[y * TX + tx]; }
-        st_agent(a.part + ((size_t)blockIdx.x * 2 + 0) * a.C + c, sa);
-        st_agent(a.part + ((size_t)blockIdx.x * 2 + 1) * a.C + c, sb);
+        if (!a.ticket) {                             // a separate launch combines the lists (flin_finish_kernel)
+            a.part[((size_t)blockIdx.x * 2 + 0) * a.C + c] = sa;
+            a.part[((size_t)blockIdx.x * 2 + 1) * a.C + c] = sb;
+        } else {
+            st_agent(a.part + ((size_t)blockIdx.x * 2 + 0) * a.C + c, sa);
+            st_agent(a.part + ((size_t)blockIdx.x * 2 + 1) * a.C + c, sb);
+        }
     }
+    if (!a.ticket) return;
     // two-level, fixed-order combination by whichever workgroups finish last (see column_totals)
     const int nb = gridDim.x, groups = (nb + FL_GROUP - 1) / FL_GROUP, grp = blockIdx.x / FL_GROUP;
     const int gsize = min(FL_GROUP, nb - grp * FL_GROUP);
@@ -800,6 +809,48 @@ __global__ __launch_bounds__(BLOCK) void bn_bwd_stats_kernel(const TopArgs a) {
     if (ty == 0 && c < a.C)
         bn_bwd_constants(a.cst, a.C, c, red[tx][0], red[TX + tx][0], (double)a.R, a.dgamma, a.dbeta, a.dbias);
     if (threadIdx.x == 0) st_agent(&t1[FL_MAXG], 0);
+}
+
+// The per-workgroup column sums of a launch -> the layer's record, as a launch of its own: part [nparts][2][N] summed in
+// index order (double).  MODE 0: forward statistics -> cst rows 0..3, running statistics.  MODE 1: BatchNorm-backward sums
+// -> dgamma, dbeta, zero bias gradient, cst rows 4, 5.  On replayed graphs this costs ~3 us against ~10 us for the in-kernel
+// hand-over (tickets, agent-scope exchanges that have to be waited for): the default (pcf_hip_set_flin_finish).
+struct FinishArgs {
+    const float* part; int nparts, N; long long R;
+    float* cst;
+    const float* gamma; const float* beta; float* running_mean; float* running_var; float eps, momentum;
+    float* dgamma; float* dbeta; float* dbias;
+};
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void flin_finish_kernel(const FinishArgs a) {
+    __shared__ double red[2][BLOCK];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < a.N) {
+        double t1 = 0.0, t2 = 0.0;
+        int q = sl;
+        for (; q + 8 < a.nparts; q += 16) {
+            s1 += (double)a.part[((size_t)q * 2 + 0) * a.N + c]; s2 += (double)a.part[((size_t)q * 2 + 1) * a.N + c];
+            t1 += (double)a.part[((size_t)(q + 8) * 2 + 0) * a.N + c]; t2 += (double)a.part[((size_t)(q + 8) * 2 + 1) * a.N + c];
+        }
+        if (q < a.nparts) { s1 += (double)a.part[((size_t)q * 2 + 0) * a.N + c]; s2 += (double)a.part[((size_t)q * 2 + 1) * a.N + c]; }
+        s1 += t1; s2 += t2;
+    }
+    red[0][threadIdx.x] = s1; red[1][threadIdx.x] = s2;
+    __syncthreads();
+    if (threadIdx.x < 32 && c < a.N) {
+        double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < BLOCK / 32; ++i) { a1 += red[0][i * 32 + cl]; a2 += red[1][i * 32 + cl]; }
+        if (MODE == 0) bn_fwd_constants(a.cst, a.N, c, a1, a2, (double)a.R, a.gamma, a.beta, a.running_mean, a.running_var, a.eps, a.momentum);
+        else bn_bwd_constants(a.cst, a.N, c, a1, a2, (double)a.R, a.dgamma, a.dbeta, a.dbias);
+    }
+}
+static int g_finish_launch = 1;
+template <int MODE>
+static int launch_finish(const FinishArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(flin_finish_kernel<MODE>, dim3(ceil_div(a.N, 32)), dim3(BLOCK), 0, s, a);
+    return check_launch("flin_finish_kernel");
 }
 
 // ---- host ------------------------------------------------------------------------------------------------------------
@@ -846,6 +897,10 @@ size_t pcf_hip_flin_workspace_bytes(long long rows, int c_out, int c_in) {
     return std::max(partials, slabs) + 256;
 }
 int pcf_hip_flin_ticket_ints(void) { return 8192; }
+int pcf_hip_set_flin_finish(int separate_launch) {
+    pcf::g_finish_launch = separate_launch ? 1 : 0;
+    return pcf::ok();
+}
 int pcf_hip_set_flin_split_k(int mode) {
     if (mode < -1 || mode > 1) return pcf::fail(PCF_E_BADARG, "set_flin_split_k: mode is -1 (automatic), 0 (off) or 1 (on)");
     pcf::g_split_k = mode;
@@ -869,24 +924,33 @@ int pcf_hip_flin_forward(const float* A, long long M, int K, const float* pre, i
     g.gamma = gamma; g.beta = beta; g.running_mean = running_mean; g.running_var = running_var; g.eps = eps; g.momentum = momentum;
     const bool vec = vec_ok(A, K) && vec_ok(W, K) && (!side || vec_ok(side, K)) && (!pre || vec_ok(pre, K));
     hipStream_t s = (hipStream_t)stream;
+    const bool finish = cst && g_finish_launch;      // statistics combined by a launch of their own
+    if (finish) g.ticket = nullptr;
+    int nparts = 0;
     if (vec && split_k_pays(M, N, K)) {
         const int xt = ceil_div(N, 32);
         PCF_REQUIRE(xt * (FL_MAXG + 1) <= pcf_hip_flin_ticket_ints(), "flin_forward: too many output channels");
-        hipLaunchKernelGGL(flin_fwd_sk_kernel, dim3(xt, rows_grid(ceil_div(M, 32), xt)), dim3(BLOCK), 0, s, g);
-        return check_launch("flin_fwd_sk_kernel");
-    }
-    if (N <= 32) {
+        nparts = rows_grid(ceil_div(M, 32), xt);
+        hipLaunchKernelGGL(flin_fwd_sk_kernel, dim3(xt, nparts), dim3(BLOCK), 0, s, g);
+    } else if (N <= 32) {
         dim3 grid(1, rows_grid(ceil_div(M, 128), 1));
+        nparts = grid.y;
         if (vec) hipLaunchKernelGGL((flin_fwd_kernel<4, 1, true>), grid, dim3(BLOCK), 0, s, g);
         else hipLaunchKernelGGL((flin_fwd_kernel<4, 1, false>), grid, dim3(BLOCK), 0, s, g);
     } else {
         const int xt = ceil_div(N, 64);
         PCF_REQUIRE(xt * (FL_MAXG + 1) <= pcf_hip_flin_ticket_ints(), "flin_forward: too many output channels");
         dim3 grid(xt, rows_grid(ceil_div(M, 64), xt));
+        nparts = grid.y;
         if (vec) hipLaunchKernelGGL((flin_fwd_kernel<2, 2, true>), grid, dim3(BLOCK), 0, s, g);
         else hipLaunchKernelGGL((flin_fwd_kernel<2, 2, false>), grid, dim3(BLOCK), 0, s, g);
     }
-    return check_launch("flin_fwd_kernel");
+    if (int e = check_launch("flin_fwd_kernel")) return e;
+    if (!finish) return ok();
+    FinishArgs f{};
+    f.part = g.part; f.nparts = nparts; f.N = N; f.R = M; f.cst = cst; f.gamma = gamma; f.beta = beta;
+    f.running_mean = running_mean; f.running_var = running_var; f.eps = eps; f.momentum = momentum;
+    return launch_finish<0>(f, s);
 }
 
 int pcf_hip_flin_backward_input(const float* dy, const float* z, const float* cst, int act, long long M, int K, const float* W,
@@ -904,24 +968,32 @@ int pcf_hip_flin_backward_input(const float* dy, const float* z, const float* cs
     g.M = (int)M; g.N = N; g.K = K;
     const bool vec = vec_ok(dy, K) && vec_ok(z, K) && vec_ok(W, N) && vec_ok(cst, K);
     hipStream_t s = (hipStream_t)stream;
+    const bool finish = cstp && g_finish_launch;
+    if (finish) g.ticket = nullptr;
+    int nparts = 0;
     if (vec && split_k_pays(M, N, K)) {
         const int xt = ceil_div(N, 32);
         PCF_REQUIRE(xt * (FL_MAXG + 1) <= pcf_hip_flin_ticket_ints(), "flin_backward_input: too many input channels");
-        hipLaunchKernelGGL(flin_bwd_in_sk_kernel, dim3(xt, rows_grid(ceil_div(M, 32), xt)), dim3(BLOCK), 0, s, g);
-        return check_launch("flin_bwd_in_sk_kernel");
-    }
-    if (N <= 32) {
+        nparts = rows_grid(ceil_div(M, 32), xt);
+        hipLaunchKernelGGL(flin_bwd_in_sk_kernel, dim3(xt, nparts), dim3(BLOCK), 0, s, g);
+    } else if (N <= 32) {
         dim3 grid(1, rows_grid(ceil_div(M, 128), 1));
+        nparts = grid.y;
         if (vec) hipLaunchKernelGGL((flin_bwd_in_kernel<4, 1, true>), grid, dim3(BLOCK), 0, s, g);
         else hipLaunchKernelGGL((flin_bwd_in_kernel<4, 1, false>), grid, dim3(BLOCK), 0, s, g);
     } else {
         const int xt = ceil_div(N, 64);
         PCF_REQUIRE(xt * (FL_MAXG + 1) <= pcf_hip_flin_ticket_ints(), "flin_backward_input: too many input channels");
         dim3 grid(xt, rows_grid(ceil_div(M, 64), xt));
+        nparts = grid.y;
         if (vec) hipLaunchKernelGGL((flin_bwd_in_kernel<2, 2, true>), grid, dim3(BLOCK), 0, s, g);
         else hipLaunchKernelGGL((flin_bwd_in_kernel<2, 2, false>), grid, dim3(BLOCK), 0, s, g);
     }
-    return check_launch("flin_bwd_in_kernel");
+    if (int e = check_launch("flin_bwd_in_kernel")) return e;
+    if (!finish) return ok();
+    FinishArgs f{};
+    f.part = g.part; f.nparts = nparts; f.N = N; f.R = M; f.cst = cstp; f.dgamma = dgamma_p; f.dbeta = dbeta_p; f.dbias = dbias_p;
+    return launch_finish<1>(f, s);
 }
 
 int pcf_hip_flin_backward_weight_splits(long long R, int M, int N) {
@@ -992,10 +1064,14 @@ int pcf_hip_bn_backward_stats(const float* dy, const float* z, const float* res,
     const int nb = (int)std::max<long long>(1, std::min<long long>({(R + 15) / 16, want, (long long)FL_MAXY}));
     TopArgs a{};
     a.dy = dy; a.z = z; a.res = res; a.cst = cst; a.act = act; a.g = g; a.dgamma = dgamma; a.dbeta = dbeta; a.dbias = dbias;
-    a.part = static_cast<float*>(workspace); a.ticket = tickets; a.R = R; a.C = C; a.TX = tx;
+    a.part = static_cast<float*>(workspace); a.ticket = g_finish_launch ? nullptr : tickets; a.R = R; a.C = C; a.TX = tx;
     a.rows_per_block = (R + nb - 1) / nb;
     hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(nb, chunks), dim3(BLOCK), 0, (hipStream_t)stream, a);
-    return check_launch("bn_bwd_stats_kernel");
+    if (int e = check_launch("bn_bwd_stats_kernel")) return e;
+    if (!g_finish_launch) return ok();
+    FinishArgs f{};
+    f.part = a.part; f.nparts = nb; f.N = C; f.R = R; f.cst = cst; f.dgamma = dgamma; f.dbeta = dbeta; f.dbias = dbias;
+    return launch_finish<1>(f, (hipStream_t)stream);
 }
 
 }  // extern "C"

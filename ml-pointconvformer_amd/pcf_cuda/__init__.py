@@ -118,6 +118,12 @@ def read_launch_log():
     return [l for l in buf.value.decode().split('\n') if l]
 
 
+def set_flin_finish(separate_launch: bool):
+    """True (default): the statistics of the fused contraction kernels are combined by a launch of their own; False: by the
+    last workgroup of the producing kernel."""
+    _lib.pcf_hip_set_flin_finish(1 if separate_launch else 0)
+
+
 def set_flin_split_k(mode: int):
     """-1: the split-K form of the point-level Linear+BN products where it pays (default); 0: never; 1: wherever it applies."""
     if _lib.pcf_hip_set_flin_split_k(int(mode)) != 0:

@@ -579,8 +579,8 @@ def _torch_chain(x, W1, b1, g1, be1, W2, b2, g2, be2, res, act1, act2, eps=1e-5)
 
 @pytest.mark.parametrize('R,C0,C1,C2,act1,act2', [(5000, 64, 16, 32, 2, 0), (777, 256, 32, 64, 1, 2), (1300, 6, 20, 70, 2, 2),
                                                   (33, 16, 8, 8, 1, 1), (3000, 96, 48, 192, 1, 2)])
-@pytest.mark.parametrize('split_k', [-1, 1])
-def test_fused_linear_chain_kernels_against_torch(device, R, C0, C1, C2, act1, act2, split_k):
+@pytest.mark.parametrize('split_k,finish', [(-1, True), (1, True), (-1, False), (1, False)])
+def test_fused_linear_chain_kernels_against_torch(device, R, C0, C1, C2, act1, act2, split_k, finish):
     """Two chained Linear+BatchNorm layers through the four C-ABI entry points (forward with the producer's BatchNorm in the
     A-tile loader and a side output, top-of-chain statistics, dz-prologue input / weight gradients with the producer's
     statistics in the epilogue): outputs, running statistics, input gradient and all parameter gradients against float64
@@ -588,6 +588,7 @@ def test_fused_linear_chain_kernels_against_torch(device, R, C0, C1, C2, act1, a
     import pcf_fused as PF
     import pcf_cuda
     pcf_cuda.set_flin_split_k(split_k)         # 1: the 32 x 32 split-K kernels wherever K >= 64
+    pcf_cuda.set_flin_finish(finish)           # statistics combined by a launch of their own / by the last workgroup (tickets)
     g = torch.Generator().manual_seed(R + C2)
     r = lambda *s: torch.randn(*s, generator=g)
     x, W1, b1, W2, b2 = r(R, C0), r(C1, C0) / C0 ** 0.5, r(C1) * 0.1, r(C2, C1) / C1 ** 0.5, r(C2) * 0.1
@@ -641,6 +642,7 @@ def test_fused_linear_chain_kernels_against_torch(device, R, C0, C1, C2, act1, a
     assert float(db1.abs().max()) == 0.0 and float(db2.abs().max()) == 0.0          # bias in front of a batch-statistics BatchNorm
     assert float(PF._tickets(dev).abs().sum()) == 0.0                                 # the kernels leave their tickets zeroed
     pcf_cuda.set_flin_split_k(-1)
+    pcf_cuda.set_flin_finish(True)
 
 
 def test_fused_linear_rejects_bad_arguments(device):
