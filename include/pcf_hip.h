@@ -81,6 +81,7 @@ int pcf_hip_set_flin_split_k(int mode);
 /* how the per-workgroup column sums of the flin kernels become a layer's record: 1 (default) a small launch of its own,
  * 0 inside the producing kernel by the workgroup that finishes last (tickets). */
 int pcf_hip_set_flin_finish(int separate_launch);
+int pcf_hip_set_row_chain_finish(int separate_launch);   /* the same choice for the row chains of point_chain.hip */
 /* Z[M,N] = f(A)[M,K] W[N,K]^T + bias, f = act_pre(A * pre[0] + pre[1]) when `pre` (the producer's record) is given, else
  * identity; `side` (nullable) receives f(A).  cst != null: batch statistics of Z -> cst rows 0..3 and the running
  * statistics (momentum update with the unbiased variance, as nn.BatchNorm1d). */

@@ -111,8 +111,10 @@ __device__ __forceinline__ bool pass_totals(const f32x4 (&s1)[NT], const f32x4 (
         float a = 0.f;
 #pragma unroll
         for (int w = 0; w < NWAVE; ++w) a += wsum[w][v];
-        st_agent(part + (size_t)blockIdx.x * NV + v, a);
+        if (!ticket) part[(size_t)blockIdx.x * NV + v] = a;      // combined by flin_finish_kernel (its [nparts][2][NC] layout)
+        else st_agent(part + (size_t)blockIdx.x * NV + v, a);
     }
+    if (!ticket) return false;
     const int v = threadIdx.x % NV, sl = threadIdx.x / NV;
     if (gridDim.x <= PC_MAXB) {
         // up to 256 lists: ONE level, the last workgroup reads them all with 16 loads in flight per lane (a second ticket round
@@ -217,6 +219,23 @@ __device__ __forceinline__ void flush_dw(const f32x4 (&acc)[NTILE], float* red, 
     for (int t = threadIdx.x; t < NTILE * 256; t += BLOCK) outp[t] = red[t];
 }
 
+// statistics of a pass combined by the last workgroup (0, default) or by a launch of their own (1).  Measured on replayed
+// graphs: tickets 0.99-1.00 ms per layer step against 1.01 ms, 20.9 against 21.25 ms per 10cm-lite iteration -- the opposite of
+// the contraction kernels of fused_linear.hip, whose two-level hand-over over up to 1024 lists is dearer.
+static int g_pc_finish = 0;
+static inline int pc_finish_fwd(const float* part, int nparts, int C, long long R, float* cst, const float* gamma, const float* beta,
+                                float* rm, float* rv, float eps, float mom, hipStream_t s) {
+    FinishArgs f{};
+    f.part = part; f.nparts = nparts; f.N = C; f.R = R; f.cst = cst; f.gamma = gamma; f.beta = beta; f.running_mean = rm; f.running_var = rv;
+    f.eps = eps; f.momentum = mom;
+    return launch_finish<0>(f, s);
+}
+static inline int pc_finish_bwd(const float* part, int nparts, int C, long long R, float* cst, float* dgamma, float* dbeta, float* dbias,
+                                hipStream_t s) {
+    FinishArgs f{};
+    f.part = part; f.nparts = nparts; f.N = C; f.R = R; f.cst = cst; f.dgamma = dgamma; f.dbeta = dbeta; f.dbias = dbias;
+    return launch_finish<1>(f, s);
+}
 // ---- head ---------------------------------------------------------------------------------------------------------
 struct HeadArgs {
     const float* x; float* z1; float* fx; float* u;              // [R,16KI] in; [R,16NM] raw unary1 output; fx; [R,8]
@@ -946,15 +965,19 @@ __global__ __launch_bounds__(BLOCK) void pe_chain_kernel(const PeArgs a) {
 }
 
 template <int NH, int NL>
-static void pe_launch_forward(const PeArgs& a, int grid, hipStream_t s) {
+static void pe_launch_forward(const PeArgs& a, int grid, hipStream_t s, bool fin) {
     hipLaunchKernelGGL((pe_chain_kernel<NH, NL, 1, true>), dim3(grid), dim3(BLOCK), 0, s, a);
+    if (fin) (void)pc_finish_fwd(a.part, grid, 16 * NH, a.R, a.cst1, a.gamma1, a.beta1, a.rmean1, a.rvar1, a.eps, a.mom1, s);
     hipLaunchKernelGGL((pe_chain_kernel<NH, NL, 2, true>), dim3(grid), dim3(BLOCK), 0, s, a);
+    if (fin) (void)pc_finish_fwd(a.part, grid, 16 * NL, a.R, a.cst2, a.gamma2, a.beta2, a.rmean2, a.rvar2, a.eps, a.mom2, s);
     hipLaunchKernelGGL((pe_chain_kernel<NH, NL, 3, true>), dim3(grid), dim3(BLOCK), 0, s, a);
 }
 template <int NH, int NL>
-static void pe_launch_backward(const PeArgs& a, int grid, hipStream_t s) {
+static void pe_launch_backward(const PeArgs& a, int grid, hipStream_t s, bool fin) {
     hipLaunchKernelGGL((pe_chain_kernel<NH, NL, 1, false>), dim3(grid), dim3(BLOCK), 0, s, a);
+    if (fin) (void)pc_finish_bwd(a.part, grid, 16 * NL, a.R, a.cst2, a.dgamma2, a.dbeta2, a.db2, s);
     hipLaunchKernelGGL((pe_chain_kernel<NH, NL, 2, false>), dim3(grid), dim3(BLOCK), 0, s, a);
+    if (fin) (void)pc_finish_bwd(a.part, grid, 16 * NH, a.R, a.cst1, a.dgamma1, a.dbeta1, a.db1, s);
     hipLaunchKernelGGL((pe_chain_kernel<NH, NL, 3, false>), dim3(grid), dim3(BLOCK), 0, s, a);
 }
 
@@ -1041,8 +1064,12 @@ int pcf_hip_point_head_forward(const float* x, long long R, int c_in, int mid, i
     a.eps = eps; a.mom1 = mom1; a.mom2 = mom2; a.part = static_cast<float*>(workspace); a.ticket = tickets; a.R = R;
     hipStream_t s = (hipStream_t)stream;
     const int grid = pc_grid(R);
+    const bool fin = g_pc_finish != 0;
+    if (fin) a.ticket = nullptr;
     hipLaunchKernelGGL((head_fwd_kernel<4, 1, 2, 1>), dim3(grid), dim3(BLOCK), 0, s, a);
+    if (fin) (void)pc_finish_fwd(a.part, grid, mid, R, cst1, gamma1, beta1, rmean1, rvar1, eps, mom1, s);
     hipLaunchKernelGGL((head_fwd_kernel<4, 1, 2, 2>), dim3(grid), dim3(BLOCK), 0, s, a);
+    if (fin) (void)pc_finish_fwd(a.part, grid, g, R, cst2, gamma2, beta2, rmean2, rvar2, eps, mom2, s);
     hipLaunchKernelGGL((head_fwd_kernel<4, 1, 2, 3>), dim3(grid), dim3(BLOCK), 0, s, a);
     return check_launch("head_fwd_kernel<1,2,3>");
 }
@@ -1077,8 +1104,12 @@ int pcf_hip_point_head_backward(const float* dfx, const float* du, const float* 
     a.g1 = w;
     hipStream_t s = (hipStream_t)stream;
     const int grid = pc_grid(R);
+    const bool fin = g_pc_finish != 0;
+    if (fin) a.ticket = nullptr;
     hipLaunchKernelGGL((head_bwd_kernel<4, 1, 2, 1>), dim3(grid), dim3(BLOCK), 0, s, a);
+    if (fin) (void)pc_finish_bwd(a.part, grid, g, R, cst2, dgamma2, dbeta2, db2, s);
     hipLaunchKernelGGL((head_bwd_kernel<4, 1, 2, 2>), dim3(grid), dim3(BLOCK), 0, s, a);
+    if (fin) (void)pc_finish_bwd(a.part, grid, mid, R, cst1, dgamma1, dbeta1, db1, s);
     hipLaunchKernelGGL((head_bwd_kernel<4, 1, 2, 3>), dim3(grid), dim3(BLOCK), 0, s, a);
     if (int e = check_launch("head_bwd_kernel<1,2,3>")) return e;
     DwReduceArgs r{};
@@ -1132,8 +1163,12 @@ int pcf_hip_point_tail_forward(const float* agg, long long R, int c_agg, int c_h
     a.eps = eps; a.mom3 = mom3; a.mom4 = mom4; a.part = static_cast<float*>(workspace); a.ticket = tickets; a.R = R;
     hipStream_t s = (hipStream_t)stream;
     const int grid = pc_grid(R);
+    const bool fin = g_pc_finish != 0;
+    if (fin) a.ticket = nullptr;
     hipLaunchKernelGGL((tail_fwd_kernel<16, 2, 4, 1>), dim3(grid), dim3(BLOCK), 0, s, a);
+    if (fin) (void)pc_finish_fwd(a.part, grid, c_half, R, cst3, gamma3, beta3, rmean3, rvar3, eps, mom3, s);
     hipLaunchKernelGGL((tail_fwd_kernel<16, 2, 4, 2>), dim3(grid), dim3(BLOCK), 0, s, a);
+    if (fin) (void)pc_finish_fwd(a.part, grid, c_out, R, cst4, gamma4, beta4, rmean4, rvar4, eps, mom4, s);
     return check_launch("tail_fwd_kernel<1,2>");
 }
 
@@ -1164,8 +1199,12 @@ int pcf_hip_point_tail_backward(const float* dout, const float* res, const float
     a.pdw4 = w;
     hipStream_t s = (hipStream_t)stream;
     const int grid = pc_grid(R);
+    const bool fin = g_pc_finish != 0;
+    if (fin) a.ticket = nullptr;
     hipLaunchKernelGGL((tail_bwd_kernel<16, 2, 4, 1>), dim3(grid), dim3(BLOCK), 0, s, a);
+    if (fin) (void)pc_finish_bwd(a.part, grid, c_out, R, cst4, dgamma4, dbeta4, db4, s);
     hipLaunchKernelGGL((tail_bwd_kernel<16, 2, 4, 2>), dim3(grid), dim3(BLOCK), 0, s, a);
+    if (fin) (void)pc_finish_bwd(a.part, grid, c_half, R, cst3, dgamma3, dbeta3, db3, s);
     hipLaunchKernelGGL((tail_bwd_kernel<16, 2, 4, 3>), dim3(grid), dim3(BLOCK), 0, s, a);
     if (int e = check_launch("tail_bwd_kernel<1,2,3>")) return e;
     DwReduceArgs r{};
@@ -1212,9 +1251,11 @@ int pcf_hip_pe_chain_forward(const float* rel, long long E, int hidden, int c_ou
     a.eps = eps; a.mom1 = mom1; a.mom2 = mom2; a.part = static_cast<float*>(workspace); a.ticket = tickets; a.R = E;
     hipStream_t s = (hipStream_t)stream;
     const int grid = pe_grid(E);
-    if (hidden == 16) pe_launch_forward<1, 1>(a, grid, s);
-    else if (hidden == 32) pe_launch_forward<2, 2>(a, grid, s);
-    else pe_launch_forward<4, 2>(a, grid, s);
+    const bool fin = g_pc_finish != 0;
+    if (fin) a.ticket = nullptr;
+    if (hidden == 16) pe_launch_forward<1, 1>(a, grid, s, fin);
+    else if (hidden == 32) pe_launch_forward<2, 2>(a, grid, s, fin);
+    else pe_launch_forward<4, 2>(a, grid, s, fin);
     return check_launch("pe_chain_kernel<forward>");
 }
 
@@ -1244,9 +1285,11 @@ int pcf_hip_pe_chain_backward(const float* dout, const float* rel, long long E, 
     a.pdw2 = w; w += (size_t)grid * nl * nh * 256;
     a.pdw1 = w;
     hipStream_t s = (hipStream_t)stream;
-    if (hidden == 16) pe_launch_backward<1, 1>(a, grid, s);
-    else if (hidden == 32) pe_launch_backward<2, 2>(a, grid, s);
-    else pe_launch_backward<4, 2>(a, grid, s);
+    const bool fin = g_pc_finish != 0;
+    if (fin) a.ticket = nullptr;
+    if (hidden == 16) pe_launch_backward<1, 1>(a, grid, s, fin);
+    else if (hidden == 32) pe_launch_backward<2, 2>(a, grid, s, fin);
+    else pe_launch_backward<4, 2>(a, grid, s, fin);
     if (int e = check_launch("pe_chain_kernel<backward>")) return e;
     DwReduceArgs r{};
     r.n = 2; r.nblocks = grid;
@@ -1255,6 +1298,12 @@ int pcf_hip_pe_chain_backward(const float* dout, const float* rel, long long E, 
     r.block0[0] = 0; r.block0[1] = r.tiles[0] * 4; r.block0[2] = r.block0[1] + r.tiles[1] * 4;
     hipLaunchKernelGGL(dw_reduce_kernel, dim3(r.block0[2]), dim3(1024), 0, s, r);
     return check_launch("dw_reduce_kernel");
+}
+
+// how the row chains' per-workgroup column sums become a layer's record: 1 a small launch of its own, 0 the last workgroup
+int pcf_hip_set_row_chain_finish(int separate_launch) {
+    pcf::g_pc_finish = separate_launch ? 1 : 0;
+    return pcf::ok();
 }
 
 }  // extern "C"

@@ -124,6 +124,11 @@ def set_flin_finish(separate_launch: bool):
     _lib.pcf_hip_set_flin_finish(1 if separate_launch else 0)
 
 
+def set_row_chain_finish(separate_launch: bool):
+    """The same choice as set_flin_finish for the row chains (PCFLayer head / tail, pe_convs)."""
+    _lib.pcf_hip_set_row_chain_finish(1 if separate_launch else 0)
+
+
 def set_flin_split_k(mode: int):
     """-1: the split-K form of the point-level Linear+BN products where it pays (default); 0: never; 1: wherever it applies."""
     if _lib.pcf_hip_set_flin_split_k(int(mode)) != 0:
