@@ -145,15 +145,25 @@ __device__ __forceinline__ void insert_key(unsigned long long (&best)[KMAX], uns
     if (key < best[0]) best[0] = key;
 }
 
-template <int KMAX>
+// SELF: the queries are the reference points themselves.  Thread t then takes the t-th point of the CELL-SORTED copy, so the
+// lanes of a wave hold neighbouring queries: the same cells, the same trip counts, the candidates in cache -- instead of
+// 64 unrelated ring walks when the cloud arrives in arbitrary order.  Results are per query and do not depend on the order.
+template <int KMAX, bool SELF>
 __global__ __launch_bounds__(BLOCK) void knn_grid_kernel(const float* __restrict__ query, const int32_t* __restrict__ query_off,
                                                          int n_seg, int n_query, const SegGrid* __restrict__ grids,
                                                          const int32_t* __restrict__ cell_start,
                                                          const float4* __restrict__ sorted, int K, int64_t* __restrict__ out) {
-    const int q = blockIdx.x * BLOCK + threadIdx.x;
-    if (q >= n_query) return;
+    const int t = blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= n_query) return;
+    int q = t;
+    float qx, qy, qz;
+    if (SELF) {
+        const float4 me = sorted[t];
+        q = __float_as_int(me.w); qx = me.x; qy = me.y; qz = me.z;
+    } else {
+        qx = query[3 * (size_t)q]; qy = query[3 * (size_t)q + 1]; qz = query[3 * (size_t)q + 2];
+    }
     const SegGrid g = grids[seg_of(query_off, n_seg, q)];
-    const float qx = query[3 * (size_t)q], qy = query[3 * (size_t)q + 1], qz = query[3 * (size_t)q + 2];
     unsigned long long best[KMAX];
 #pragma unroll
     for (int s = 0; s < KMAX; ++s) best[s] = ~0ull;
@@ -172,12 +182,19 @@ __global__ __launch_bounds__(BLOCK) void knn_grid_kernel(const float* __restrict
             const bool xedge = (ix == cx - r) || (ix == cx + r);
             for (int iy = y0; iy <= y1; ++iy) {
                 const bool xyedge = xedge || (iy == cy - r) || (iy == cy + r);
-                // on a face of the shell every z is new; inside only the two end caps are
-                const int zstep = xyedge ? 1 : max(2 * r, 1);
-                for (int iz = xyedge ? z0 : cz - r; iz <= z1; iz += zstep) {
-                    if (iz < z0) continue;
-                    const int c = g.cell_base + (ix * g.dy + iy) * g.dz + iz;
-                    const int beg = cell_start[c], end = cell_start[c + 1];
+                // On a face of the shell every z of the column is new: the cells of a column are consecutive, and so are their
+                // points in the sorted copy -- ONE range (two dependent loads) instead of one per cell.  Inside the shell only
+                // the two end caps are new.  (The ring walk is a chain of dependent loads: its length is what costs; fetching
+                // the bounds of six columns before scanning any of them was measured too: slower.)
+                const int col = g.cell_base + (ix * g.dy + iy) * g.dz;
+                int zb[2], ze[2], nr = 0;
+                if (xyedge) { zb[0] = z0; ze[0] = z1; nr = 1; }
+                else {
+                    if (cz - r >= z0) { zb[nr] = cz - r; ze[nr] = cz - r; ++nr; }
+                    if (r > 0 && cz + r <= z1) { zb[nr] = cz + r; ze[nr] = cz + r; ++nr; }
+                }
+                for (int i = 0; i < nr; ++i) {
+                    const int beg = cell_start[col + zb[i]], end = cell_start[col + ze[i] + 1];
                     for (int p = beg; p < end; ++p) {
                         const float4 rp = sorted[p];
                         const float ddx = __fsub_rn(rp.x, qx), ddy = __fsub_rn(rp.y, qy), ddz = __fsub_rn(rp.z, qz);
@@ -264,10 +281,18 @@ int pcf_hip_knn_grid(const float* ref, const float* query, const int32_t* ref_of
     if (int e = exclusive_scan_i32(counts, chunks, start, w.n_cells, true, s)) return e;      // leaves counts zeroed
     hipLaunchKernelGGL(cell_fill_kernel, dim3(pgrid), dim3(BLOCK), 0, s, ref, n_ref, cellpt, start, counts, sorted);
     const dim3 qgrid(ceil_div(n_query, BLOCK));
-    if (K <= 8) hipLaunchKernelGGL(knn_grid_kernel<8>, qgrid, dim3(BLOCK), 0, s, query, query_off, n_seg, n_query, grids, start, sorted, K, out);
-    else if (K <= 16) hipLaunchKernelGGL(knn_grid_kernel<16>, qgrid, dim3(BLOCK), 0, s, query, query_off, n_seg, n_query, grids, start, sorted, K, out);
-    else if (K <= 32) hipLaunchKernelGGL(knn_grid_kernel<32>, qgrid, dim3(BLOCK), 0, s, query, query_off, n_seg, n_query, grids, start, sorted, K, out);
-    else hipLaunchKernelGGL(knn_grid_kernel<64>, qgrid, dim3(BLOCK), 0, s, query, query_off, n_seg, n_query, grids, start, sorted, K, out);
+    // self neighbourhoods (same array, same segments): queries in cell order
+    const bool self = query == ref && n_query == n_ref && query_off == ref_off;
+#define PCF_KNN_LAUNCH(KM)                                                                                                              \
+    do {                                                                                                                                \
+        if (self) hipLaunchKernelGGL((knn_grid_kernel<KM, true>), qgrid, dim3(BLOCK), 0, s, query, query_off, n_seg, n_query, grids, start, sorted, K, out); \
+        else hipLaunchKernelGGL((knn_grid_kernel<KM, false>), qgrid, dim3(BLOCK), 0, s, query, query_off, n_seg, n_query, grids, start, sorted, K, out); \
+    } while (0)
+    if (K <= 8) PCF_KNN_LAUNCH(8);
+    else if (K <= 16) PCF_KNN_LAUNCH(16);
+    else if (K <= 32) PCF_KNN_LAUNCH(32);
+    else PCF_KNN_LAUNCH(64);
+#undef PCF_KNN_LAUNCH
 #undef PCF_HIP
     return check_launch("knn_grid: ring search");
 }
