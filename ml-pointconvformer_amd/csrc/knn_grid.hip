@@ -42,18 +42,51 @@ __device__ __forceinline__ int seg_of(const int32_t* off, int n_seg, int i) {
 __device__ __forceinline__ int cell_coord(float v, float o, float inv_h) { return (int)floorf((v - o) * inv_h); }
 
 // ---- 1. per-sample bounding box and grid geometry ------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void seg_grid_kernel(const float* __restrict__ ref, const int32_t* __restrict__ ref_off,
-                                                         int K, SegGrid* __restrict__ grids) {
+// Bounding boxes in two steps: SEG_SLICES workgroups per sample reduce a slice each (one workgroup walking a 36k-point sample
+// alone is 140 dependent rounds of loads: 25 us, seven times per training iteration), the grid kernel combines the slices.
+constexpr int SEG_SLICES = 32;
+__global__ __launch_bounds__(BLOCK) void seg_bbox_kernel(const float* __restrict__ ref, const int32_t* __restrict__ ref_off,
+                                                         float* __restrict__ bbox) {
     __shared__ float smin[3][BLOCK], smax[3][BLOCK];
-    const int s = blockIdx.x;
+    const int s = blockIdx.x, sl = blockIdx.y;
     const int r0 = ref_off[s], r1 = ref_off[s + 1];
     float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-    for (int i = r0 + threadIdx.x; i < r1; i += BLOCK)
+    for (int i = r0 + sl * BLOCK + threadIdx.x; i < r1; i += SEG_SLICES * BLOCK)
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             const float v = ref[3 * (size_t)i + a];
             mn[a] = fminf(mn[a], v);
             mx[a] = fmaxf(mx[a], v);
+        }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { smin[a][threadIdx.x] = mn[a]; smax[a][threadIdx.x] = mx[a]; }
+    __syncthreads();
+    for (int st = BLOCK / 2; st > 0; st >>= 1) {
+        if (threadIdx.x < st)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                smin[a][threadIdx.x] = fminf(smin[a][threadIdx.x], smin[a][threadIdx.x + st]);
+                smax[a][threadIdx.x] = fmaxf(smax[a][threadIdx.x], smax[a][threadIdx.x + st]);
+            }
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) {
+        bbox[((size_t)s * SEG_SLICES + sl) * 6 + threadIdx.x] = smin[threadIdx.x][0];
+        bbox[((size_t)s * SEG_SLICES + sl) * 6 + 3 + threadIdx.x] = smax[threadIdx.x][0];
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void seg_grid_kernel(const float* __restrict__ bbox, const int32_t* __restrict__ ref_off,
+                                                         int K, SegGrid* __restrict__ grids) {
+    __shared__ float smin[3][BLOCK], smax[3][BLOCK];
+    const int s = blockIdx.x;
+    const int r0 = ref_off[s], r1 = ref_off[s + 1];
+    float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    if (threadIdx.x < SEG_SLICES)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = bbox[((size_t)s * SEG_SLICES + threadIdx.x) * 6 + a];
+            mx[a] = bbox[((size_t)s * SEG_SLICES + threadIdx.x) * 6 + 3 + a];
         }
 #pragma unroll
     for (int a = 0; a < 3; ++a) { smin[a][threadIdx.x] = mn[a]; smax[a][threadIdx.x] = mx[a]; }
@@ -224,7 +257,7 @@ __global__ __launch_bounds__(BLOCK) void knn_grid_kernel(const float* __restrict
 int exclusive_scan_i32(int32_t* counts, int32_t* chunk_tmp, int32_t* out, int n, bool clear_counts, hipStream_t s);   // knn.hip
 
 struct GridWs {
-    size_t off_grids, off_cellpt, off_counts, off_start, off_chunks, off_sorted, bytes;
+    size_t off_grids, off_bbox, off_cellpt, off_counts, off_start, off_chunks, off_sorted, bytes;
     int n_cells;
 };
 static GridWs grid_plan(int n_ref, int n_seg) {
@@ -232,6 +265,7 @@ static GridWs grid_plan(int n_ref, int n_seg) {
     w.n_cells = 2 * n_ref + 8 * n_seg;
     size_t off = 0;
     w.off_grids = off;  off = align_up(off + (size_t)std::max(n_seg, 1) * sizeof(SegGrid), 256);
+    w.off_bbox = off;   off = align_up(off + (size_t)std::max(n_seg, 1) * SEG_SLICES * 6 * 4, 256);
     w.off_cellpt = off; off = align_up(off + (size_t)std::max(n_ref, 1) * 4, 256);
     w.off_counts = off; off = align_up(off + (size_t)(w.n_cells + 1) * 4, 256);
     w.off_start = off;  off = align_up(off + (size_t)(w.n_cells + 2) * 4, 256);
@@ -274,7 +308,9 @@ int pcf_hip_knn_grid(const float* ref, const float* query, const int32_t* ref_of
         if (e_ != hipSuccess) return fail(PCF_E_LAUNCH, "knn_grid: %s", hipGetErrorString(e_)); \
     } while (0)
     PCF_HIP(hipMemsetAsync(counts, 0, (size_t)(w.n_cells + 1) * 4, s));
-    hipLaunchKernelGGL(seg_grid_kernel, dim3(n_seg), dim3(BLOCK), 0, s, ref, ref_off, K, grids);
+    float* bbox = reinterpret_cast<float*>(ws + w.off_bbox);
+    hipLaunchKernelGGL(seg_bbox_kernel, dim3(n_seg, SEG_SLICES), dim3(BLOCK), 0, s, ref, ref_off, bbox);
+    hipLaunchKernelGGL(seg_grid_kernel, dim3(n_seg), dim3(BLOCK), 0, s, bbox, ref_off, K, grids);
     const int pgrid = std::max(1, std::min(ceil_div(std::max(n_ref, 1), BLOCK), 2048));
     hipLaunchKernelGGL(cell_count_kernel, dim3(pgrid), dim3(BLOCK), 0, s, ref, ref_off, n_seg, n_ref, grids, cellpt, counts);
     if (int e = check_launch("knn_grid: cell histogram")) return e;
