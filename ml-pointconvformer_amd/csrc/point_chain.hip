@@ -17,7 +17,8 @@
 // Weight fragments (forward and transposed) and BatchNorm constants live in LDS, weight-gradient tiles are accumulated per
 // wave as outer products over the tile's 16 rows (operands turned through 16 x 20 LDS tiles as in edge_chain_bwd.hip) and
 // reduced by one final launch; statistics are finished by the last workgroup of the pass (agent-scope atomics, no L2
-// write-back: flin_common.h).  fp32 throughout, exact products; deterministic.
+// write-back: flin_common.h).  fp32 throughout, exact products; deterministic.  The same machinery runs the two-layer
+// positional-encoding MLPs of the strided / transposed PointConvs over the EDGES (pe_chain_kernel, below).
 #include <algorithm>
 
 #include "edge_chain.h"
@@ -85,10 +86,11 @@ __device__ __forceinline__ f32x4 drelu4(f32x4 d, f32x4 pre) {
 __device__ __forceinline__ f32x4 cst_row4(const float* cst, int C, int which, int c0) { return v4(ld4(cst + which * C + c0)); }
 
 // Column sums of a pass: every lane holds sums of its four channels per 16-channel tile; fold the 16 row lanes, the four
-// waves (fixed order) and publish the workgroup's [2][NC] list.  The lists are combined in two levels, each by the workgroup
-// that arrives last (tickets): the PC_GROUP lists of a group, then the group sums -- every load of a level is in flight at
-// once, where one level over 512 lists costs 13 us of dependent agent-scope loads.  Fixed summation order; double from the
-// group level on.  True in the one workgroup that ends up with the totals in tot[2 NC].
+// waves (fixed order) and publish the workgroup's [2][NC] list.  The lists are combined by the workgroup that arrives last
+// (tickets; hand-over rules in flin_common.h): up to PC_MAXB lists in ONE level with 16 loads in flight per lane, more (the
+// edge-row chains: up to 2048) in two levels -- the PC_GROUP lists of a group, then the group sums.  Fixed summation order,
+// double from the first combination on.  True in the one workgroup that ends up with the totals in tot[2 NC].  ticket == null:
+// the lists are left for flin_finish_kernel (a launch of its own; pcf_hip_set_row_chain_finish).
 template <int NT>
 __device__ __forceinline__ bool pass_totals(const f32x4 (&s1)[NT], const f32x4 (&s2)[NT], float* part, int* ticket, double* tot) {
     constexpr int NC = 16 * NT, NV = 2 * NC;
