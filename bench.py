@@ -360,6 +360,32 @@ def cpu_baseline_subsample(xyzs, nrms, grid, n0, iters=5):
                       if kind == 'reference' else f'full workload, numpy restatement, median {med * 1e3:.1f} ms'}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) outside a torchrun environment: start one fresh process per GPU ourselves, as the
+    reference's launcher does (run_distributed.sh:1: torch.distributed.launch --nproc_per_node), before this process has
+    touched the GPU: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+    bench.py <same arguments>`.  The children inherit stdout (rank 0 prints the one JSON line); the parent only waits and
+    exits with the launcher's return code.  Inside a torchrun environment (WORLD_SIZE set) this is a no-op and --gpus is
+    taken from the environment."""
+    if args.gpus <= 1 or 'WORLD_SIZE' in os.environ or 'RANK' in os.environ:
+        return
+    import socket
+    import subprocess
+    n_visible = torch.cuda.device_count()          # counting devices does not initialise the GPU runtime
+    if n_visible < args.gpus and os.environ.get('PCF_DIST_REHEARSE') != '1':          # rehearsal: every rank on cuda:0, gloo
+        sys.exit(f'bench.py: --gpus {args.gpus} but only {n_visible} GPU(s) visible')
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')           # dmabuf IPC: what RCCL needs on this pool
+    env.setdefault('OMP_NUM_THREADS', str(max(1, _host_cores() // args.gpus)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print('bench: launching ' + ' '.join(cmd), file=sys.stderr, flush=True)
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -384,6 +410,7 @@ def main():
     ap.add_argument('--deterministic', action='store_true',
                     help='grad_x by CSR gather-reduce (bitwise reproducible) instead of float atomics')
     args = ap.parse_args()
+    self_launch(args)
     if args.workload == 'train':
         return bench_train(args)
     if args.points is None:
@@ -395,10 +422,7 @@ def main():
 
     import pcf_dist
     rank, world, local_rank = pcf_dist.env_rank()
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit('bench.py: launch N>1 with torch.distributed.run (one process per GPU)')
-        args.gpus = world
+    args.gpus = world
     assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback for the HIP path)'
     rank, world, local_rank, dev = pcf_dist.setup('nccl')
 

@@ -52,6 +52,12 @@ const char* pcf_hip_last_error(void);
  * assert WHICH kernels a model configuration dispatches to. */
 void pcf_hip_launch_log_enable(int on);
 size_t pcf_hip_launch_log_read(char* buf, size_t capacity);
+/* Buffers are cleared (and the handful of device-to-device copies made) by ordinary kernels of this library, never by
+ * hipMemsetAsync / hipMemcpyAsync: captured into a HIP graph those calls become memset / memcpy nodes, and a replayed
+ * training iteration whose kNN cell histogram was cleared by a memset node ran the dependent counting sort on uncleared
+ * memory (DESIGN.md "graph replay fault").  pcf_hip_zero_host runs the zero kernel's per-thread indexing (head bytes,
+ * 16-byte body, tail bytes) on HOST memory over `blocks` x 256 emulated threads -- a test hook that needs no GPU. */
+void pcf_hip_zero_host(void* p, size_t bytes, int blocks);
 /* Kernel family for the aggregate shapes the matrix-core kernels cover: 0 default, 1 LDS-tiled kernels (cross-check),
  * 2 tiled matrix-core kernels everywhere.  Process-wide; the environment (PCF_AGG_LDS=1 / PCF_AGG_TILED=1) only sets
  * the initial value. */

@@ -1145,7 +1145,7 @@ int aggregate_backward(const float* gout, const float* x, const int64_t* idx, co
     if (int e = check_dims("aggregate backward", B, N, Nout, K, Ci, Ca, Cm, H, guid != nullptr)) return e;
     const int total = B * Nout;
     if (gx && (size_t)B * N * Ci > 0) {
-        hipError_t e = hipMemsetAsync(gx, 0, (size_t)B * N * Ci * sizeof(float), stream);
+        hipError_t e = zero_async(gx, (size_t)B * N * Ci * sizeof(float), stream);
         if (e != hipSuccess) return fail(PCF_E_LAUNCH, "aggregate backward: memset grad_x: %s", hipGetErrorString(e));
     }
     if (total == 0) return ok();
@@ -1254,7 +1254,7 @@ int pcf_hip_pcf_backward_csr(const float* grad_out, const float* x, const int32_
     hipStream_t s = (hipStream_t)stream;
     float* contrib = static_cast<float*>(workspace);
     if (B * Nout == 0) {
-        if ((size_t)B * N * Ci) (void)hipMemsetAsync(grad_x, 0, (size_t)B * N * Ci * 4, s);
+        if ((size_t)B * N * Ci) (void)zero_async(grad_x, (size_t)B * N * Ci * 4, s);
         return ok();
     }
     if (int e = aggregate_backward(grad_out, x, idx, guid, w, nullptr, nullptr, contrib, grad_guid, grad_w, nullptr, B, N,

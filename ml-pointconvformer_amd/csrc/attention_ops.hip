@@ -236,8 +236,8 @@ int pcf_hip_layer_norm_backward(const float* dy, const float* x, const float* ga
     PCF_REQUIRE(dgamma && dbeta, "layer_norm_backward: null pointer");
     hipStream_t s = (hipStream_t)stream;
     if (R == 0) {
-        (void)hipMemsetAsync(dgamma, 0, (size_t)C * 4, s);
-        (void)hipMemsetAsync(dbeta, 0, (size_t)C * 4, s);
+        (void)zero_async(dgamma, (size_t)C * 4, s);
+        (void)zero_async(dbeta, (size_t)C * 4, s);
         return ok();
     }
     PCF_REQUIRE(dy && x && gamma && mean && rstd && dx && workspace && aligned16(workspace) &&
@@ -249,8 +249,7 @@ int pcf_hip_layer_norm_backward(const float* dy, const float* x, const float* ga
     // part is [nb][2C]: dgamma = columns 0..C-1, dbeta = columns C..2C-1 of the slab sum (into a scratch row, then split)
     float* tot = part + (size_t)nb * 2 * C;
     if (int e = slab_sum(part, tot, 2 * C, nb, s)) return e;
-    if (hipMemcpyAsync(dgamma, tot, (size_t)C * 4, hipMemcpyDeviceToDevice, s) != hipSuccess ||
-        hipMemcpyAsync(dbeta, tot + C, (size_t)C * 4, hipMemcpyDeviceToDevice, s) != hipSuccess)
+    if (copy_async(dgamma, tot, (size_t)C * 4, s) != hipSuccess || copy_async(dbeta, tot + C, (size_t)C * 4, s) != hipSuccess)
         return fail(PCF_E_LAUNCH, "layer_norm_backward: copy");
     return ok();
 }

@@ -283,7 +283,7 @@ int pcf_hip_bnact_backward_res(const float* z, const float* residual, const floa
     hipStream_t s = (hipStream_t)stream;
     const bool bn = mean != nullptr;
     if (R == 0) {
-        if (bn) { (void)hipMemsetAsync(dgamma, 0, (size_t)C * 4, s); (void)hipMemsetAsync(dbeta, 0, (size_t)C * 4, s); }
+        if (bn) { (void)zero_async(dgamma, (size_t)C * 4, s); (void)zero_async(dbeta, (size_t)C * 4, s); }
         return ok();
     }
     PCF_REQUIRE(z && dy && dz && (!bn || (rstd && gamma && beta && dgamma && dbeta)), "bnact_backward: null pointer");
@@ -325,8 +325,8 @@ int pcf_hip_linear_backward(const float* dz, const float* x, const float* W, lon
                 "linear_backward: null pointer or small workspace");
     hipStream_t s = (hipStream_t)stream;
     if (R == 0) {
-        (void)hipMemsetAsync(dW, 0, (size_t)Cout * Cin * 4, s);
-        if (db) (void)hipMemsetAsync(db, 0, (size_t)Cout * 4, s);
+        (void)zero_async(dW, (size_t)Cout * Cin * 4, s);
+        if (db) (void)zero_async(db, (size_t)Cout * 4, s);
         return ok();
     }
     PCF_REQUIRE(dz && x, "linear_backward: null pointer");

@@ -41,9 +41,51 @@ int check_launch(const char* what) {
     return ok();
 }
 
+__global__ __launch_bounds__(BLOCK) void zero_kernel(unsigned char* p, size_t n) {
+    zero_item(p, n, (size_t)blockIdx.x * BLOCK + threadIdx.x, (size_t)gridDim.x * BLOCK);
+}
+
+// 16-byte pieces where both pointers allow it, bytes otherwise (the few copies of the library are a handful of floats)
+__global__ __launch_bounds__(BLOCK) void copy_kernel(unsigned char* dst, const unsigned char* src, size_t n) {
+    const size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x, T = (size_t)gridDim.x * BLOCK;
+    if (((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) == 0) {
+        const size_t quads = n / 16;
+        for (size_t i = t; i < quads; i += T) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
+        for (size_t i = quads * 16 + t; i < n; i += T) dst[i] = src[i];
+    } else {
+        for (size_t i = t; i < n; i += T) dst[i] = src[i];
+    }
+}
+
+static int fill_grid(size_t bytes) {
+    const size_t blocks = (bytes / 16 + BLOCK - 1) / BLOCK;
+    return (int)(blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks));
+}
+
+hipError_t zero_async(void* p, size_t bytes, hipStream_t stream) {
+    if (bytes == 0) return hipSuccess;
+    if (!p) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(zero_kernel, dim3(fill_grid(bytes)), dim3(BLOCK), 0, stream, static_cast<unsigned char*>(p), bytes);
+    return hipGetLastError();
+}
+
+hipError_t copy_async(void* dst, const void* src, size_t bytes, hipStream_t stream) {
+    if (bytes == 0) return hipSuccess;
+    if (!dst || !src) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(copy_kernel, dim3(fill_grid(bytes)), dim3(BLOCK), 0, stream, static_cast<unsigned char*>(dst),
+                       static_cast<const unsigned char*>(src), bytes);
+    return hipGetLastError();
+}
+
 }  // namespace pcf
 
 extern "C" {
+// Host emulation of zero_kernel's indexing over `blocks` x BLOCK threads (test hook: no GPU needed).
+void pcf_hip_zero_host(void* p, size_t bytes, int blocks) {
+    const size_t T = (size_t)(blocks < 1 ? 1 : blocks) * pcf::BLOCK;
+    for (size_t t = 0; t < T; ++t) pcf::zero_item(static_cast<unsigned char*>(p), bytes, t, T);
+}
+
 const char* pcf_hip_version(void) { return "pcf_hip 0.1 gfx950"; }
 const char* pcf_hip_last_error(void) { return pcf::err_buf(); }
 

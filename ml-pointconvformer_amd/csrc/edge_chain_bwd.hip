@@ -948,14 +948,14 @@ static int chain_backward_impl(const float* ukey, float* dukey, bool wn_only, co
         PCF_REQUIRE(W[l] && b[l] && gamma[l] && beta[l] && dW[l] && db[l] && dgamma[l] && dbeta[l],
                     "pcf_chain_backward: null parameter of layer %d", l);
         if (E == 0) {
-            (void)hipMemsetAsync(db[l], 0, (size_t)couts[l] * 4, s);
-            (void)hipMemsetAsync(dW[l], 0, (size_t)couts[l] * cins[l] * 4, s);
-            (void)hipMemsetAsync(dgamma[l], 0, (size_t)couts[l] * 4, s);
-            (void)hipMemsetAsync(dbeta[l], 0, (size_t)couts[l] * 4, s);
+            (void)zero_async(db[l], (size_t)couts[l] * 4, s);
+            (void)zero_async(dW[l], (size_t)couts[l] * cins[l] * 4, s);
+            (void)zero_async(dgamma[l], (size_t)couts[l] * 4, s);
+            (void)zero_async(dbeta[l], (size_t)couts[l] * 4, s);
         }
     }
     const long long batches = E / rows_per_batch;
-    if (!wn_only && batches * N > 0 && hipMemsetAsync(du, 0, (size_t)batches * N * CH * 4, s) != hipSuccess)
+    if (!wn_only && batches * N > 0 && zero_async(du, (size_t)batches * N * CH * 4, s) != hipSuccess)
         return fail(PCF_E_LAUNCH, "pcf_chain_backward: memset");
     if (E == 0) return ok();
     PCF_REQUIRE(vi && a2_acc && dw && (wn_only || (idx && h1_acc && dscore)), "pcf_chain_backward: null pointer");

@@ -747,14 +747,14 @@ int pcf_hip_rowlin_backward_ex(const float* x, const float* dy, long long R, int
     if (gadd && rows_per_batch > 0) {
         const size_t n = (size_t)(R / rows_per_batch) * gN * Cout;
         if (n) {
-            hipError_t e = hipMemsetAsync(dgadd, 0, n * 4, s);
+            hipError_t e = zero_async(dgadd, n * 4, s);
             if (e != hipSuccess) return fail(PCF_E_LAUNCH, "rowlin_backward: memset: %s", hipGetErrorString(e));
         }
     }
     if (R == 0) {
-        (void)hipMemsetAsync(dW, 0, (size_t)Cout * Cin * 4, s);
-        (void)hipMemsetAsync(db, 0, (size_t)Cout * 4, s);
-        if (bn) { (void)hipMemsetAsync(dgamma, 0, (size_t)Cout * 4, s); (void)hipMemsetAsync(dbeta, 0, (size_t)Cout * 4, s); }
+        (void)zero_async(dW, (size_t)Cout * Cin * 4, s);
+        (void)zero_async(db, (size_t)Cout * 4, s);
+        if (bn) { (void)zero_async(dgamma, (size_t)Cout * 4, s); (void)zero_async(dbeta, (size_t)Cout * 4, s); }
         return ok();
     }
     PCF_REQUIRE(x && dy, "rowlin_backward: null pointer");

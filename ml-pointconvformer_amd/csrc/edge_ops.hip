@@ -289,7 +289,7 @@ int pcf_hip_scatter_add_rows(const float* grad_rows, const int64_t* idx, float* 
     hipStream_t s = (hipStream_t)stream;
     if ((size_t)B * N * C) {
         PCF_REQUIRE(grad_table, "scatter_add_rows: grad_table is null");
-        hipError_t e = hipMemsetAsync(grad_table, 0, (size_t)B * N * C * 4, s);
+        hipError_t e = zero_async(grad_table, (size_t)B * N * C * 4, s);
         if (e != hipSuccess) return fail(PCF_E_LAUNCH, "scatter_add_rows: memset: %s", hipGetErrorString(e));
     }
     const long long total = (long long)B * S * C;
@@ -317,7 +317,7 @@ int pcf_hip_gather_max_backward(const float* grad_out, const int64_t* idx, const
     hipStream_t s = (hipStream_t)stream;
     if ((size_t)B * N * C) {
         PCF_REQUIRE(grad_table, "gather_max_backward: grad_table is null");
-        hipError_t e = hipMemsetAsync(grad_table, 0, (size_t)B * N * C * 4, s);
+        hipError_t e = zero_async(grad_table, (size_t)B * N * C * 4, s);
         if (e != hipSuccess) return fail(PCF_E_LAUNCH, "gather_max_backward: memset: %s", hipGetErrorString(e));
     }
     const long long total = (long long)B * M * C;
@@ -372,7 +372,7 @@ int pcf_hip_guidance_diff_backward(const float* ds, const int64_t* idx, const ui
     hipStream_t st = (hipStream_t)stream;
     if ((size_t)B * N * G) {
         PCF_REQUIRE(dgx, "guidance_diff_backward: dgx is null");
-        hipError_t e = hipMemsetAsync(dgx, 0, (size_t)B * N * G * 4, st);
+        hipError_t e = zero_async(dgx, (size_t)B * N * G * 4, st);
         if (e != hipSuccess) return fail(PCF_E_LAUNCH, "guidance_diff_backward: memset: %s", hipGetErrorString(e));
     }
     const long long units = (long long)B * M * (G + P);

@@ -263,8 +263,8 @@ int pcf_hip_grid_subsample(const float* points, const float* features, const int
         hipError_t e_ = (call);                                                                      \
         if (e_ != hipSuccess) return fail(PCF_E_LAUNCH, "grid_subsample: %s", hipGetErrorString(e_)); \
     } while (0)
-    PCF_HIP(hipMemsetAsync(out_total, 0, 2 * sizeof(int32_t), s));          // [0] voxels, [1] status bits
-    if (n_seg) PCF_HIP(hipMemsetAsync(out_seg_counts, 0, (size_t)n_seg * 4, s));
+    PCF_HIP(zero_async(out_total, 2 * sizeof(int32_t), s));          // [0] voxels, [1] status bits
+    if (n_seg) PCF_HIP(zero_async(out_seg_counts, (size_t)n_seg * 4, s));
     if (n_points == 0 || n_seg == 0) return ok();
     PCF_REQUIRE(points && out_points && (F == 0 || (features && out_features)), "grid_subsample: null pointer");
     const SubWs w = sub_plan(n_points, n_seg);
@@ -310,7 +310,7 @@ int pcf_hip_voxelize(const float* points, int n_points, double voxel_size, int m
                 n_points, voxel_size, mode);
     PCF_REQUIRE(out_total, "voxelize: null count output");
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(out_total, 0, 2 * sizeof(int32_t), s) != hipSuccess) return fail(PCF_E_LAUNCH, "voxelize: memset");
+    if (zero_async(out_total, 2 * sizeof(int32_t), s) != hipSuccess) return fail(PCF_E_LAUNCH, "voxelize: memset");
     if (n_points == 0) return ok();
     const SubWs w = sub_plan(n_points, 1);
     PCF_REQUIRE(points && out_index && workspace && aligned16(workspace) && workspace_bytes >= w.bytes,

@@ -273,7 +273,7 @@ __global__ __launch_bounds__(BLOCK) void scan_write_kernel(int32_t* __restrict__
 // out[i] = sum of counts[0..i) for i in [0, n]; chunk_tmp holds ceil(n / 1024) ints.  (also used by knn_grid.hip)
 int exclusive_scan_i32(int32_t* counts, int32_t* chunk_tmp, int32_t* out, int n, bool clear_counts, hipStream_t s) {
     if (n <= 0) {
-        hipError_t e = hipMemsetAsync(out, 0, 4, s);
+        hipError_t e = zero_async(out, 4, s);
         return e == hipSuccess ? ok() : fail(PCF_E_LAUNCH, "scan: %s", hipGetErrorString(e));
     }
     const int nchunks = ceil_div(n, SCAN_CHUNK);
@@ -290,8 +290,9 @@ __device__ __forceinline__ void csr_fill_body(const int64_t* __restrict__ idx,
     for (long long e = (long long)bx * BLOCK + threadIdx.x; e < edges; e += (long long)gx * BLOCK) {
         const int64_t t = idx[e];
         if (t >= 0 && t < total_points) {
-            const int pos = atomicAdd(&cursor[t], 1);
-            keys[inv_idx[t] + pos] = (uint32_t)e;
+            const long long slot = (long long)inv_idx[t] + atomicAdd(&cursor[t], 1);
+            // inside the table whenever the histogram was clear on entry; never a wild store if it was not
+            if (slot >= 0 && slot < edges) keys[slot] = (uint32_t)e;
         }
     }
 }
@@ -317,7 +318,7 @@ __device__ __forceinline__ void csr_sort_small_body(const uint32_t* __restrict__
                                                                int32_t* __restrict__ big_count, long long edges, int bx, int gx) {
     const int lane = lane_id();
     // slots past the last valid edge (out-of-range neighbour indices leave some) read as zero
-    for (long long e = inv_idx[total_points] + (long long)bx * BLOCK + threadIdx.x; e < edges;
+    for (long long e = (long long)max(inv_idx[total_points], 0) + (long long)bx * BLOCK + threadIdx.x; e < edges;
          e += (long long)gx * BLOCK) {
         inv_n[e] = 0;
         inv_k[e] = 0;
@@ -325,7 +326,7 @@ __device__ __forceinline__ void csr_sort_small_body(const uint32_t* __restrict__
     for (int t = bx * NWAVE + wave_id(); t < total_points; t += gx * NWAVE) {
         const int beg = inv_idx[t], end = inv_idx[t + 1];
         const int d = end - beg;
-        if (d <= 0) continue;
+        if (d <= 0 || beg < 0 || end > edges) continue;          // the second and third only with a corrupted offset table
         if (d > WAVE) {
             if (lane == 0) big_list[atomicAdd(big_count, 1)] = t;
             continue;
@@ -360,12 +361,14 @@ __device__ __forceinline__ void csr_sort_large_body(const uint32_t* __restrict__
                                                                const int32_t* __restrict__ inv_idx, int K,
                                                                int32_t* __restrict__ inv_n, uint8_t* __restrict__ inv_k,
                                                                const int32_t* __restrict__ big_list,
-                                                               const int32_t* __restrict__ big_count, int bx, int gx) {
+                                                               const int32_t* __restrict__ big_count, long long edges, int bx,
+                                                               int gx) {
     __shared__ uint32_t s[SORT_LDS];
     const int nbig = *big_count;
     for (int w = bx; w < nbig; w += gx) {
         const int t = big_list[w];
         const int beg = inv_idx[t], d = inv_idx[t + 1] - beg;
+        if (beg < 0 || d <= 0 || (long long)beg + d > edges) continue;      // uniform per workgroup; corrupted table only
         if (d <= SORT_LDS) {
             int n2 = 1;
             while (n2 < d) n2 <<= 1;
@@ -400,8 +403,8 @@ __global__ __launch_bounds__(BLOCK) void csr_sort_large_kernel(const uint32_t* _
                                                                const int32_t* __restrict__ inv_idx, int K,
                                                                int32_t* __restrict__ inv_n, uint8_t* __restrict__ inv_k,
                                                                const int32_t* __restrict__ big_list,
-                                                               const int32_t* __restrict__ big_count) {
-    csr_sort_large_body(keys, inv_idx, K, inv_n, inv_k, big_list, big_count, blockIdx.x, gridDim.x);
+                                                               const int32_t* __restrict__ big_count, long long edges) {
+    csr_sort_large_body(keys, inv_idx, K, inv_n, inv_k, big_list, big_count, edges, blockIdx.x, gridDim.x);
 }
 
 struct CsrWs {
@@ -465,7 +468,7 @@ __global__ __launch_bounds__(BLOCK) void csr_sort_small_batch_kernel(const CsrBa
 }
 __global__ __launch_bounds__(BLOCK) void csr_sort_large_batch_kernel(const CsrBatch b) {
     const CsrProblem& q = b.p[blockIdx.y];
-    csr_sort_large_body(q.keys, q.xb, q.K, q.nb, q.kb, q.big, q.bigc, blockIdx.x, gridDim.x);
+    csr_sort_large_body(q.keys, q.xb, q.K, q.nb, q.kb, q.big, q.bigc, q.edges, blockIdx.x, gridDim.x);
 }
 
 // workspace of a batch: [counts + big-bucket count of every table (zeroed by one memset)] [chunk sums, keys, big lists]
@@ -562,13 +565,13 @@ int pcf_hip_knn_inverse(const int64_t* idx, int32_t* inv_neighbors, uint8_t* inv
         int32_t* xb = inv_idx + (size_t)b * (total_points + 1);
         if (total_points == 0) {
             if (edges) {
-                PCF_HIP(hipMemsetAsync(nb, 0, (size_t)edges * 4, s));
-                PCF_HIP(hipMemsetAsync(kb, 0, (size_t)edges, s));
+                PCF_HIP(zero_async(nb, (size_t)edges * 4, s));
+                PCF_HIP(zero_async(kb, (size_t)edges, s));
             }
-            PCF_HIP(hipMemsetAsync(xb, 0, 4, s));
+            PCF_HIP(zero_async(xb, 4, s));
             continue;
         }
-        PCF_HIP(hipMemsetAsync(counts, 0, (size_t)(total_points + 1) * 4, s));       // histogram + big-bucket count
+        PCF_HIP(zero_async(counts, (size_t)(total_points + 1) * 4, s));       // histogram + big-bucket count
         if (edges) {
             hipLaunchKernelGGL(csr_count_kernel, dim3(egrid), dim3(BLOCK), 0, s, ib, counts, edges, total_points);
             if (int e = check_launch("knn_inverse histogram")) return e;
@@ -582,7 +585,7 @@ int pcf_hip_knn_inverse(const int64_t* idx, int32_t* inv_neighbors, uint8_t* inv
             const int sgrid = std::max(1, std::min(ceil_div(total_points, NWAVE), 8192));
             hipLaunchKernelGGL(csr_sort_small_kernel, dim3(sgrid), dim3(BLOCK), 0, s, keys, xb, total_points, K, nb, kb,
                                big, bigc, edges);
-            hipLaunchKernelGGL(csr_sort_large_kernel, dim3(1024), dim3(BLOCK), 0, s, keys, xb, K, nb, kb, big, bigc);
+            hipLaunchKernelGGL(csr_sort_large_kernel, dim3(1024), dim3(BLOCK), 0, s, keys, xb, K, nb, kb, big, bigc, edges);
             if (int e = check_launch("knn_inverse fill/sort")) return e;
         }
     }
@@ -618,7 +621,7 @@ int pcf_hip_knn_inverse_batched(int n_tables, const int64_t* const* idx, int32_t
                 "knn_inverse_batched: workspace too small or misaligned (%zu < %zu)", workspace_bytes, w.bytes);
     hipStream_t s = (hipStream_t)stream;
     char* ws = static_cast<char*>(workspace);
-    if (hipMemsetAsync(ws, 0, w.zero_bytes, s) != hipSuccess) return fail(PCF_E_LAUNCH, "knn_inverse_batched: memset failed");
+    if (zero_async(ws, w.zero_bytes, s) != hipSuccess) return fail(PCF_E_LAUNCH, "knn_inverse_batched: memset failed");
     for (int base = 0; base < n_tables; base += CSR_BATCH_MAX) {
         const int nb = std::min(CSR_BATCH_MAX, n_tables - base);
         CsrBatch b{};

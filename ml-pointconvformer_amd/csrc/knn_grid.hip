@@ -162,7 +162,9 @@ __global__ __launch_bounds__(BLOCK) void cell_fill_kernel(const float* __restric
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n_ref; i += gridDim.x * BLOCK) {
         const int c = cell_of_pt[i];
         const int pos = cell_start[c] + atomicAdd(&cursor[c], 1);
-        sorted[pos] = make_float4(ref[3 * (size_t)i], ref[3 * (size_t)i + 1], ref[3 * (size_t)i + 2], __int_as_float(i));
+        // pos < n_ref whenever the histogram was clear on entry; the guard turns a dirty workspace into wrong neighbours
+        // (which the parity tests see) instead of a 16-byte write up to +-32 GB away from the table
+        if ((unsigned int)pos < (unsigned int)n_ref) sorted[pos] = make_float4(ref[3 * (size_t)i], ref[3 * (size_t)i + 1], ref[3 * (size_t)i + 2], __int_as_float(i));
     }
 }
 
@@ -185,7 +187,8 @@ template <int KMAX, bool SELF>
 __global__ __launch_bounds__(BLOCK) void knn_grid_kernel(const float* __restrict__ query, const int32_t* __restrict__ query_off,
                                                          int n_seg, int n_query, const SegGrid* __restrict__ grids,
                                                          const int32_t* __restrict__ cell_start,
-                                                         const float4* __restrict__ sorted, int K, int64_t* __restrict__ out) {
+                                                         const float4* __restrict__ sorted, int n_ref, int K,
+                                                         int64_t* __restrict__ out) {
     const int t = blockIdx.x * BLOCK + threadIdx.x;
     if (t >= n_query) return;
     int q = t;
@@ -193,6 +196,7 @@ __global__ __launch_bounds__(BLOCK) void knn_grid_kernel(const float* __restrict
     if (SELF) {
         const float4 me = sorted[t];
         q = __float_as_int(me.w); qx = me.x; qy = me.y; qz = me.z;
+        if ((unsigned int)q >= (unsigned int)n_query) return;          // a sorted copy that was not filled properly: no wild row
     } else {
         qx = query[3 * (size_t)q]; qy = query[3 * (size_t)q + 1]; qz = query[3 * (size_t)q + 2];
     }
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(BLOCK) void knn_grid_kernel(const float* __restrict
                     if (r > 0 && cz + r <= z1) { zb[nr] = cz + r; ze[nr] = cz + r; ++nr; }
                 }
                 for (int i = 0; i < nr; ++i) {
-                    const int beg = cell_start[col + zb[i]], end = cell_start[col + ze[i] + 1];
+                    const int beg = max(cell_start[col + zb[i]], 0), end = min(cell_start[col + ze[i] + 1], n_ref);
                     for (int p = beg; p < end; ++p) {
                         const float4 rp = sorted[p];
                         const float ddx = __fsub_rn(rp.x, qx), ddy = __fsub_rn(rp.y, qy), ddz = __fsub_rn(rp.z, qz);
@@ -307,7 +311,7 @@ int pcf_hip_knn_grid(const float* ref, const float* query, const int32_t* ref_of
         hipError_t e_ = (call);                                                              \
         if (e_ != hipSuccess) return fail(PCF_E_LAUNCH, "knn_grid: %s", hipGetErrorString(e_)); \
     } while (0)
-    PCF_HIP(hipMemsetAsync(counts, 0, (size_t)(w.n_cells + 1) * 4, s));
+    PCF_HIP(zero_async(counts, (size_t)(w.n_cells + 1) * 4, s));
     float* bbox = reinterpret_cast<float*>(ws + w.off_bbox);
     hipLaunchKernelGGL(seg_bbox_kernel, dim3(n_seg, SEG_SLICES), dim3(BLOCK), 0, s, ref, ref_off, bbox);
     hipLaunchKernelGGL(seg_grid_kernel, dim3(n_seg), dim3(BLOCK), 0, s, bbox, ref_off, K, grids);
@@ -321,8 +325,8 @@ int pcf_hip_knn_grid(const float* ref, const float* query, const int32_t* ref_of
     const bool self = query == ref && n_query == n_ref && query_off == ref_off;
 #define PCF_KNN_LAUNCH(KM)                                                                                                              \
     do {                                                                                                                                \
-        if (self) hipLaunchKernelGGL((knn_grid_kernel<KM, true>), qgrid, dim3(BLOCK), 0, s, query, query_off, n_seg, n_query, grids, start, sorted, K, out); \
-        else hipLaunchKernelGGL((knn_grid_kernel<KM, false>), qgrid, dim3(BLOCK), 0, s, query, query_off, n_seg, n_query, grids, start, sorted, K, out); \
+        if (self) hipLaunchKernelGGL((knn_grid_kernel<KM, true>), qgrid, dim3(BLOCK), 0, s, query, query_off, n_seg, n_query, grids, start, sorted, n_ref, K, out); \
+        else hipLaunchKernelGGL((knn_grid_kernel<KM, false>), qgrid, dim3(BLOCK), 0, s, query, query_off, n_seg, n_query, grids, start, sorted, n_ref, K, out); \
     } while (0)
     if (K <= 8) PCF_KNN_LAUNCH(8);
     else if (K <= 16) PCF_KNN_LAUNCH(16);

@@ -27,6 +27,27 @@ void note_launch(const char* what);
         if (!(cond)) return ::pcf::fail(PCF_E_BADARG, __VA_ARGS__);   \
     } while (0)
 
+// Zero-fill / device-to-device copy as ORDINARY KERNELS on `stream` (common.hip).  The library never calls hipMemsetAsync /
+// hipMemcpyAsync: under stream capture those become memset / memcpy graph nodes, and a replayed graph whose cell
+// histogram was cleared by a memset node ran the dependent kernel on uncleared memory ("graph replay fault").
+// A kernel node is ordered and made visible exactly like every other kernel of the chain.
+hipError_t zero_async(void* p, size_t bytes, hipStream_t stream);
+hipError_t copy_async(void* dst, const void* src, size_t bytes, hipStream_t stream);
+
+// One thread's share of zeroing bytes [0, n) at p (any alignment): the unaligned head and tail bytes go to the first 15
+// threads, the 16-byte-aligned body to everyone in 16-byte stores.  Shared by the kernel and its host emulation
+// (pcf_hip_zero_host, tests/test_abi_cpu.py).
+__host__ __device__ inline void zero_item(unsigned char* p, size_t n, size_t t, size_t T) {
+    size_t head = (16 - (reinterpret_cast<uintptr_t>(p) & 15)) & 15;
+    if (head > n) head = n;
+    const size_t quads = (n - head) / 16;
+    const size_t tail = n - head - quads * 16;
+    if (t < head) p[t] = 0;
+    uint4* body = reinterpret_cast<uint4*>(p + head);
+    for (size_t i = t; i < quads; i += T) body[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (t < tail) p[head + quads * 16 + t] = 0;
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -94,8 +94,8 @@ int pcf_hip_pconv_linear_backward(const float* grad_out, const float* x, const i
                 "pconv_linear_backward: workspace too small or misaligned (%zu < %zu)", workspace_bytes, ws.bytes);
     PCF_REQUIRE(grad_lin_w && grad_lin_b, "pconv_linear_backward: null grad_lin_w / grad_lin_b");
     if (total == 0) {
-        (void)hipMemsetAsync(grad_lin_w, 0, (size_t)Co * J * 4, s);
-        (void)hipMemsetAsync(grad_lin_b, 0, (size_t)Co * 4, s);
+        (void)zero_async(grad_lin_w, (size_t)Co * J * 4, s);
+        (void)zero_async(grad_lin_b, (size_t)Co * 4, s);
         return aggregate_backward(nullptr, x, idx, nullptr, w, add, grad_x, nullptr, nullptr, grad_w, grad_add, B, N,
                                   Nout, K, Ci, Ca, Cm, 1, s);
     }
@@ -133,9 +133,9 @@ int pcf_hip_pconv_linear_opt_backward(const float* grad_out, const float* x, con
                 "pconv_linear_opt_backward: null gradient pointer");
     char* wsp = static_cast<char*>(workspace);
     if (total == 0) {
-        (void)hipMemsetAsync(grad_lin_w, 0, (size_t)Co * J * 4, s);
-        (void)hipMemsetAsync(grad_lin_b, 0, (size_t)Co * 4, s);
-        if ((size_t)B * N * Ci) (void)hipMemsetAsync(grad_x, 0, (size_t)B * N * Ci * 4, s);
+        (void)zero_async(grad_lin_w, (size_t)Co * J * 4, s);
+        (void)zero_async(grad_lin_b, (size_t)Co * 4, s);
+        if ((size_t)B * N * Ci) (void)zero_async(grad_x, (size_t)B * N * Ci * 4, s);
         return ok();
     }
     PCF_REQUIRE(grad_out && lin_w && pconv_out, "pconv_linear_opt_backward: null pointer");

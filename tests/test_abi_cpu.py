@@ -70,3 +70,25 @@ def test_c_abi_argument_errors_without_gpu():
     assert rc == -1 and b'K must be in [1,64]' in lib.pcf_hip_last_error()
     lib.pcf_hip_knn_inverse_workspace_bytes.restype = ctypes.c_size_t
     assert lib.pcf_hip_knn_inverse_workspace_bytes(1, 100, 16, 100) > 100 * 16 * 4
+
+
+def test_zero_kernel_indexing_on_host():
+    """csrc/pcf_common.h:zero_item -- the per-thread share of the library's zero-fill kernel (which replaces every
+    hipMemsetAsync, so that a captured iteration holds no memset nodes) -- run on host memory: every byte of [p, p+n) is
+    cleared and not one byte outside, for all alignments of p, sizes around the 16-byte body granularity, one and many
+    emulated workgroups."""
+    import numpy as np
+    import pcf_cuda
+    lib = ctypes.CDLL(pcf_cuda.library_path())
+    lib.pcf_hip_zero_host.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    lib.pcf_hip_zero_host.restype = None
+    sizes = list(range(0, 70)) + [255, 256, 257, 4095, 4096, 4097, 86236, 156928, 1 << 20]
+    for blocks in (1, 3, 64):
+        for n in sizes:
+            for shift in (0, 1, 3, 4, 8, 15):
+                buf = np.full(n + 64, 0xAB, np.uint8)
+                base = buf.ctypes.data
+                start = (-base) % 16 + 16 + shift                # buf[start] sits `shift` bytes past a 16-byte boundary
+                lib.pcf_hip_zero_host(ctypes.c_void_p(base + start), n, blocks)
+                assert not buf[start:start + n].any(), (blocks, n, shift)
+                assert (buf[:start] == 0xAB).all() and (buf[start + n:] == 0xAB).all(), (blocks, n, shift)
