@@ -123,6 +123,13 @@ class GradBucket:
         if self.world > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
 
+    def attach(self):
+        """The averaged gradients without the copy back: every `.grad` becomes its view of the bucket (contiguous, at a fixed
+        address -- what a captured optimizer step needs).  Parameters that had no gradient this step get the zeros `pack`
+        wrote for them, as DDP hands the optimizer zeros for unused parameters."""
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+
     def unpack(self):
         grads = [p.grad for p in self.params if p.grad is not None]
         views = [v for p, v in zip(self.params, self.views) if p.grad is not None]

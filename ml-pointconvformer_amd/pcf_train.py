@@ -133,8 +133,9 @@ def clip_grad_norm_(optimizer, max_norm):
     return total
 
 
-def training_iteration(model, optimizer, criterion, cfg, batch, edges=None):
-    """One optimisation step on one packed batch; returns the loss tensor (no host sync)."""
+def forward_backward(model, criterion, cfg, batch, edges=None):
+    """First half of an iteration (train_ScanNet_DDP_WarmUP.py:382-419): post-kNN, inverse CSR, forward, loss, backward.
+    Leaves the gradients in `.grad`; returns the detached loss (no host sync)."""
     features, pointclouds, target, norms, points_stored = batch
     es, ef, ep, inv = edges if edges is not None else build_edges(cfg, pointclouds, points_stored)
     pred = model(features, pointclouds, es, ef, ep, norms, *inv)
@@ -144,13 +145,70 @@ def training_iteration(model, optimizer, criterion, cfg, batch, edges=None):
     else:
         loss = criterion(logits, target)
     loss.backward()
+    return loss.detach()
+
+
+def optimizer_step(optimizer, max_grad_norm=10):
+    """Second half (train_ScanNet_DDP_WarmUP.py:421-424): clip_grad_norm_(10), optimizer step, gradients dropped."""
     if hasattr(optimizer, 'last_grad_norm'):          # pcf_optim.FusedAdamW: norm, clip and update in one pass
-        optimizer.step(max_grad_norm=10)
+        optimizer.step(max_grad_norm=max_grad_norm)
     else:
-        clip_grad_norm_(optimizer, 10)
+        clip_grad_norm_(optimizer, max_grad_norm)
         optimizer.step()
     optimizer.zero_grad(set_to_none=True)
-    return loss.detach()
+
+
+def training_iteration(model, optimizer, criterion, cfg, batch, edges=None):
+    """One optimisation step on one packed batch; returns the loss tensor (no host sync)."""
+    loss = forward_backward(model, criterion, cfg, batch, edges)
+    optimizer_step(optimizer)
+    return loss
+
+
+def _training_state(model, optimizer):
+    """Every tensor an optimisation step changes in place: parameters, BatchNorm buffers, the optimizer's moments and step
+    counters (torch AdamW keeps them in `state`, pcf_optim.FusedAdamW additionally in its per-group device records)."""
+    seen, out = set(), []
+
+    def add(t):
+        if torch.is_tensor(t) and t.data_ptr() not in seen:
+            seen.add(t.data_ptr())
+            out.append(t)
+    for t in list(model.parameters()) + list(model.buffers()):
+        add(t)
+    for st in optimizer.state.values():
+        for v in st.values():
+            add(v)
+    for rec in getattr(optimizer, '_recs', {}).values():
+        add(rec[0])
+    return out
+
+
+_HIP_NODE_KINDS = {0: 'kernel', 1: 'memcpy', 2: 'memset', 3: 'host', 4: 'graph', 5: 'empty', 6: 'wait_event', 7: 'event_record',
+                   8: 'ext_semaphore_signal', 9: 'ext_semaphore_wait', 10: 'mem_alloc', 11: 'mem_free'}
+
+
+def graph_node_counts(graph):
+    """{node kind: count} of a captured torch.cuda.CUDAGraph built with keep_graph=True (hipGraphGetNodes /
+    hipGraphNodeGetType through ctypes).  A captured training iteration of this package must consist of kernel nodes
+    only (tests/test_zz_graph_replay_gpu.py)."""
+    import ctypes
+    lib = ctypes.CDLL('libamdhip64.so')
+    raw = ctypes.c_void_p(graph.raw_cuda_graph())
+    n = ctypes.c_size_t(0)
+    if lib.hipGraphGetNodes(raw, None, ctypes.byref(n)) != 0:
+        raise RuntimeError('hipGraphGetNodes failed')
+    nodes = (ctypes.c_void_p * max(n.value, 1))()
+    if n.value and lib.hipGraphGetNodes(raw, nodes, ctypes.byref(n)) != 0:
+        raise RuntimeError('hipGraphGetNodes failed')
+    counts = {}
+    for i in range(n.value):
+        t = ctypes.c_int(-1)
+        if lib.hipGraphNodeGetType(ctypes.c_void_p(nodes[i]), ctypes.byref(t)) != 0:
+            raise RuntimeError('hipGraphNodeGetType failed')
+        kind = _HIP_NODE_KINDS.get(t.value, str(t.value))
+        counts[kind] = counts.get(kind, 0) + 1
+    return counts
 
 
 class GraphedTrainingStep:
@@ -160,36 +218,180 @@ class GraphedTrainingStep:
     The whole iteration is device-side (no host reads: the kNN engines are chosen from host-known sizes, offsets tables
     are cached device tensors, the optimizer is built with capturable=True so its step counters live on the device).
     A graph is tied to the shapes of its batch: this serves loops that revisit a fixed set of packed batches (the
-    benchmark's rotating pool); batches of new shapes fall back to a fresh capture.  Replaying changes parameters,
-    optimizer state and BatchNorm running statistics exactly as the eager iteration does."""
+    benchmark's rotating pool); a batch object seen for the first time is captured first.
 
-    def __init__(self, model, optimizer, criterion, cfg, warmup=2):
-        self.model, self.optimizer, self.criterion, self.cfg, self.warmup = model, optimizer, criterion, cfg, warmup
+    Every call -- the first one for a batch included -- performs EXACTLY ONE optimisation step and returns that step's
+    loss: the warm-up iterations a capture needs (lazy code-object loading, persistent buffers, allocator pools) run on a
+    snapshot of the training state (parameters, BatchNorm buffers, optimizer moments and counters) that is restored before
+    the capture, and the captured graph is then replayed once.  Each graph owns its memory pool by default
+    (`share_pool=True` lets later captures reuse the first graph's pool: correct only while graphs are replayed one at a time
+    and no tensor of one graph is read after another graph ran -- the loss returned here is, so it is cloned out of the pool).
+    The captured region holds kernel nodes only: the library clears buffers with its own kernels (csrc/common.hip), see
+    DESIGN.md "graph replay fault"."""
+
+    def __init__(self, model, optimizer, criterion, cfg, warmup=1, share_pool=False, max_graphs=16):
+        self.model, self.optimizer, self.criterion, self.cfg, self.warmup = model, optimizer, criterion, cfg, max(1, int(warmup))
+        self.share_pool, self.max_graphs = bool(share_pool), int(max_graphs)
         self.graphs = {}
         self.pool = None
+        self.keep_graph = False          # tests: keep the hipGraph_t so that its nodes can be inspected
 
     def _capture(self, batch):
+        """-> (graph, loss tensor inside the graph's pool, loss of an eager first step or None)."""
+        first = None
+        if not self.optimizer.state:
+            # a fresh optimizer creates its moments and counters in its first step: take that step eagerly -- it is this
+            # call's one optimisation step -- and capture from the state it leaves
+            first = training_iteration(self.model, self.optimizer, self.criterion, self.cfg, batch).clone()
+            torch.cuda.synchronize()
+        state = _training_state(self.model, self.optimizer)
+        saved = [t.clone() for t in state]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):          # warm-up off the capture: allocator pools, lazy kernel loading, persistent buffers
+        with torch.cuda.stream(side):          # warm-up off the capture stream, on a state that is restored below
             for _ in range(self.warmup):
                 training_iteration(self.model, self.optimizer, self.criterion, self.cfg, batch)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, pool=self.pool):
+        with torch.no_grad():
+            for t, v in zip(state, saved):
+                t.copy_(v)
+        del saved
+        g = torch.cuda.CUDAGraph(keep_graph=True) if self.keep_graph else torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=self.pool if self.share_pool else None):
             loss = training_iteration(self.model, self.optimizer, self.criterion, self.cfg, batch)
-        if self.pool is None:
+        if self.share_pool and self.pool is None:
             self.pool = g.pool()
-        return g, loss
+        return g, loss, first
 
     def __call__(self, batch):
         key = id(batch)
         hit = self.graphs.get(key)
         if hit is None:
-            hit = self.graphs[key] = self._capture(batch) + (batch,)       # keep the batch alive: the graph reads its tensors
-            return hit[1]
+            if len(self.graphs) >= self.max_graphs:          # oldest capture out (its pool returns to the allocator)
+                self.graphs.pop(next(iter(self.graphs)))
+            g, loss, first = self._capture(batch)
+            hit = self.graphs[key] = (g, loss, batch)          # keep the batch alive: the graph reads its tensors
+            if first is not None:
+                return first          # the first call on a fresh optimizer already took its one (eager) step
         if hasattr(self.optimizer, 'sync_hyperparameters'):
             self.optimizer.sync_hyperparameters()          # a scheduler's learning rate reaches the replayed kernels
         hit[0].replay()
-        return hit[1]
+        return hit[1].clone()
+
+
+class DataParallelStep:
+    """One optimisation step of data-parallel training with ONE gradient collective (the reference wraps the model in
+    DistributedDataParallel, train_ScanNet_DDP_WarmUP.py:191-195; run_distributed.sh:1 starts one process per GPU):
+
+        half 1   forward_backward on this rank's packed batch, gradients packed into the flat bucket (scaled by 1/world)
+        --       all-reduce of the bucket on the compute stream: RCCL over xGMI (gloo in the CPU tests)
+        half 2   gradients = views of the bucket, clip_grad_norm_(10), AdamW, gradients dropped
+
+    Same arithmetic as DDP + the reference's loop (mean of the rank-local gradients, then clip and step on every rank).
+    With `use_graph` half 1 is captured per packed batch and half 2 once, so a step costs two graph launches and one
+    collective on the host instead of ~2300 launches plus DDP's per-bucket hooks (the eager iteration is host-bound:
+    34 ms against 25.6 ms replayed for configPCF_10cm on one GPU).  A failed capture on ANY rank switches EVERY rank to
+    eager halves for good (agreed with one MIN all-reduce before the next gradient collective).  Every call performs exactly
+    one step (see GraphedTrainingStep for how the capture's warm-up is kept out of the training state).
+    `sync_buffers=True` broadcasts rank 0's BatchNorm running statistics before every forward, as DDP's default
+    broadcast_buffers does; they do not enter a training-mode forward, so the benchmarks leave it off."""
+
+    def __init__(self, model, optimizer, criterion, cfg, bucket, use_graph=False, sync_buffers=False, warmup=1, max_graphs=16):
+        self.model, self.optimizer, self.criterion, self.cfg, self.bucket = model, optimizer, criterion, cfg, bucket
+        self.use_graph, self.sync_buffers, self.warmup, self.max_graphs = bool(use_graph), bool(sync_buffers), max(1, int(warmup)), max_graphs
+        self.graphs, self.step_graph = {}, None
+        self.capture_failures = 0
+
+    # ---- the two halves, eager ----
+    def _half1(self, batch, edges=None):
+        loss = forward_backward(self.model, self.criterion, self.cfg, batch, edges)
+        self.bucket.pack()
+        for p in self.bucket.params:          # the bucket holds them now
+            p.grad = None
+        return loss
+
+    def _half2(self):
+        self.bucket.attach()
+        optimizer_step(self.optimizer)
+
+    def eager(self, batch, edges=None):
+        if self.sync_buffers:
+            self.bucket.sync_buffers()
+        loss = self._half1(batch, edges)
+        self.bucket.all_reduce()
+        self._half2()
+        return loss
+
+    # ---- capture ----
+    def _agree(self, ok, dev):
+        import torch.distributed as dist
+        if not (dist.is_initialized() and dist.get_world_size() > 1):
+            return ok
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item())
+
+    def _capture(self, batch):
+        dev = self.bucket.flat.device
+        first = None
+        if not self.optimizer.state:          # fresh optimizer: its first step is taken eagerly (this call's one step)
+            first = self.eager(batch).clone()
+            torch.cuda.synchronize()
+        state = _training_state(self.model, self.optimizer)
+        saved = [t.clone() for t in state]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(self.warmup):
+                self.eager(batch)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()          # no collective in flight while the capture runs
+        with torch.no_grad():
+            for t, v in zip(state, saved):
+                t.copy_(v)
+        del saved
+        ok, g, loss, gb = True, None, None, self.step_graph
+        try:
+            # other threads of the process (the collective library's watchdog) may touch the runtime during capture
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                loss = self._half1(batch)
+            if gb is None:
+                gb = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gb, capture_error_mode='thread_local'):
+                    self._half2()
+        except Exception as exc:          # capture is an optimisation of the host side, not a requirement
+            ok = False
+            self.capture_error = f'{type(exc).__name__}: {exc}'
+            self.optimizer.zero_grad(set_to_none=True)
+        torch.cuda.synchronize()
+        if not self._agree(ok, dev):
+            self.use_graph, self.graphs, self.step_graph = False, {}, None
+            self.capture_failures += 1
+            return None, None, first
+        self.step_graph = gb
+        return g, loss, first
+
+    def __call__(self, batch):
+        if not self.use_graph:
+            return self.eager(batch)
+        key = id(batch)
+        hit = self.graphs.get(key)
+        if hit is None:
+            if len(self.graphs) >= self.max_graphs:
+                self.graphs.pop(next(iter(self.graphs)))
+            g, loss, first = self._capture(batch)
+            if g is None:          # all ranks fell back together
+                return first if first is not None else self.eager(batch)
+            hit = self.graphs[key] = (g, loss, batch)
+            if first is not None:
+                return first
+        if self.sync_buffers:
+            self.bucket.sync_buffers()
+        if hasattr(self.optimizer, 'sync_hyperparameters'):
+            self.optimizer.sync_hyperparameters()
+        hit[0].replay()
+        self.bucket.all_reduce()
+        self.step_graph.replay()
+        return hit[1].clone()

@@ -228,7 +228,7 @@ class OracleDrivenModel(torch.nn.Module):
         super().__init__()
         self.net = net
 
-    def forward(self, feats, pcs, es, ef, ep, nrms):
+    def forward(self, feats, pcs, es, ef, ep, nrms, *inv):
         from oracle import pcf_oracle as O
         table = dict(self.net.named_parameters())
         table.update(dict(self.net.named_buffers()))
@@ -307,3 +307,64 @@ def test_segmentation_model_training_step_ddp_two_ranks():
         for n, gexp in want.items():
             torch.testing.assert_close(torch.from_numpy(grads[n]), gexp, rtol=1e-4, atol=1e-5 * max(1.0, float(gexp.abs().max())),
                                        msg=lambda m, n=n: f'{n}: {m}')
+
+
+def _split_step_worker(rank, world, port, out):
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    import pcf_dist
+    import pcf_train
+    _, _, _, dev = pcf_dist.setup('gloo')
+    cfg = _seg_cfg()
+    crit = torch.nn.CrossEntropyLoss(label_smoothing=0.2)
+
+    def batches():
+        res = []
+        for b in range(2):
+            feats, pcs, es, ef, ep, nrms, target = _seg_scene(pcf_dist.data_seed(300 + 10 * b, rank))
+            res.append(((feats, pcs, target, nrms, None), (es, ef, ep, (None, None, None))))
+        return res
+
+    # reference: DistributedDataParallel + the training loop's step
+    net_a = _seg_model()
+    ddp = pcf_dist.wrap_ddp(OracleDrivenModel(net_a), dev)
+    opt_a = torch.optim.SGD(net_a.parameters(), lr=0.1, momentum=0.9)
+    # this build: flat bucket, one all-reduce, gradients attached as views of the bucket
+    net_b = _seg_model()
+    bucket = pcf_dist.GradBucket(list(net_b.parameters()), list(net_b.buffers()))
+    bucket.broadcast_parameters()
+    opt_b = torch.optim.SGD(net_b.parameters(), lr=0.1, momentum=0.9)
+    step = pcf_train.DataParallelStep(OracleDrivenModel(net_b), opt_b, crit, cfg, bucket, use_graph=False, sync_buffers=True)
+    losses = []
+    for it, (batch, edges) in enumerate(batches() + batches()[:1]):
+        la = pcf_train.training_iteration(ddp, opt_a, crit, cfg, batch, edges)
+        lb = step.eager(batch, edges)
+        losses.append((float(la), float(lb)))
+        assert all(p.grad is None for p in net_b.parameters()), 'gradients are dropped after the step'
+    pa = torch.cat([p.detach().reshape(-1) for p in net_a.parameters()])
+    pb = torch.cat([p.detach().reshape(-1) for p in net_b.parameters()])
+    ba = {n: b.clone() for n, b in net_a.named_buffers()}
+    bb = {n: b.clone() for n, b in net_b.named_buffers()}
+    both = [torch.empty_like(pb) for _ in range(world)]
+    torch.distributed.all_gather(both, pb)
+    assert torch.equal(both[0], both[1]), 'ranks diverged'
+    out.put((rank, losses, float((pa - pb).abs().max()), float(pa.abs().max()),
+             max(float((ba[n].double() - bb[n].double()).abs().max()) for n in ba)))
+    pcf_dist.shutdown()
+
+
+@pytest.mark.timeout(600)
+def test_data_parallel_step_equals_ddp_two_ranks():
+    """pcf_train.DataParallelStep (flat bucket packed after backward, ONE all-reduce, gradients attached as bucket views,
+    clip + optimizer step; BatchNorm buffers broadcast from rank 0 like DDP's broadcast_buffers) against
+    DistributedDataParallel + pcf_train.training_iteration over three steps on two gloo ranks with rank-local scenes:
+    same losses, same parameters and buffers after every step's worth of updates, identical parameters on both ranks.
+    This is the eager form of what bench.py --workload train runs with N > 1 (its two halves are what gets captured)."""
+    for rank, losses, diff, scale, bdiff in _run_two(_split_step_worker):
+        for la, lb in losses:
+            assert abs(la - lb) < 1e-5 * max(1.0, abs(la)), (rank, losses)
+        assert diff < 2e-5 * max(1.0, scale), (rank, diff, scale)
+        assert bdiff < 1e-5, (rank, bdiff)
