@@ -1,0 +1,85 @@
+"""Child process of tests/test_zz_graph_replay_gpu.py: captured-and-replayed training iterations against eager ones.
+
+Runs in its own process so that a GPU memory fault (the failure this test exists for: round 2's captured
+configPCF_2cm_PTF2 iteration faulted on replay) ends this process only and is reported by the parent as a failed
+assertion with the child's output.  One JSON line per case on stdout.
+
+Per case: two models with identical parameters and two FusedAdamW optimizers; the same rotating pool of two packed
+batches; `calls` optimisation steps through pcf_train.training_iteration (eager) and through
+pcf_train.GraphedTrainingStep (capture on first sight of a batch, replay afterwards -- the fifth call is the second
+replay of the first graph, where the round-2 fault occurred)."""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'ml-pointconvformer_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+
+def run_case(name, scenes, points, calls, freeze_draws, dev):
+    import pcf_layers
+    import pcf_model
+    import pcf_train
+    cfg = pcf_train.baseline_config(name)
+    crit = torch.nn.CrossEntropyLoss(ignore_index=cfg.ignore_label, label_smoothing=cfg.label_smoothing).to(dev)
+    pool = []
+    for b in range(2):
+        sc = [pcf_train.synthetic_scene(points, cfg.grid_size, seed=7000 + 10 * b + i, device=dev) for i in range(scenes)]
+        pool.append(pcf_train.pack_batch(sc, cfg.grid_size))
+    nets, opts = [], []
+    for _ in range(2):
+        torch.manual_seed(11)
+        net = pcf_model.PointConvFormer_Segmentation(cfg).to(dev).train()
+        if freeze_draws and cfg.drop_path_rate > 0:
+            # both paths must see the same stochastic-depth factors: every block keeps its branch, scaled by 1 / keep
+            # (the DropPath code path -- no fused residual tail -- is still the one that runs)
+            for m in net.modules():
+                if isinstance(m, pcf_layers.DropPath) and m.drop_prob > 0:
+                    m.draw = (lambda x, k=1.0 - m.drop_prob: x.new_full((x.shape[0],) + (1,) * (x.dim() - 1), 1.0 / k))
+        nets.append(net)
+        opts.append(pcf_train.make_optimizer(cfg, net, capturable=True))
+    start = torch.cat([p.detach().reshape(-1) for p in nets[0].parameters()]).clone()
+    eager = [float(pcf_train.training_iteration(nets[0], opts[0], crit, cfg, pool[i % 2])) for i in range(calls)]
+    torch.cuda.synchronize()
+    gstep = pcf_train.GraphedTrainingStep(nets[1], opts[1], crit, cfg)
+    gstep.keep_graph = True
+    graphed = []
+    for i in range(calls):
+        graphed.append(float(gstep(pool[i % 2])))          # float(): synchronises, so a fault is pinned to its call
+        print(json.dumps({'progress': name, 'call': i, 'loss': graphed[-1]}), flush=True)
+    kinds = [pcf_train.graph_node_counts(g[0]) for g in gstep.graphs.values()]
+    pe = torch.cat([p.detach().reshape(-1) for p in nets[0].parameters()])
+    pg = torch.cat([p.detach().reshape(-1) for p in nets[1].parameters()])
+    de, dg = (pe - start).double(), (pg - start).double()
+    nbt = [[int(b) for n, b in net.named_buffers() if n.endswith('num_batches_tracked')] for net in nets]
+    steps = [float(o._recs[0][0][1]) for o in opts]
+    return {'case': name, 'scenes': scenes, 'points': points, 'levels': pool[0][4], 'eager_losses': eager, 'graph_losses': graphed,
+            'node_kinds': kinds, 'update_cosine': float((de @ dg) / (de.norm() * dg.norm() + 1e-30)),
+            'finite': bool(torch.isfinite(pg).all()), 'num_batches_tracked': [[min(v), max(v)] for v in nbt],
+            'optimizer_steps': steps, 'frozen_draws': bool(freeze_draws)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--cases', default='small')
+    args = ap.parse_args()
+    dev = torch.device('cuda:0')
+    small = [('configPCF_10cm_lite', 2, 3000), ('configPCF_10cm', 2, 3000), ('configPCF_5cm', 1, 6000),
+             ('configPCF_2cm_PTF2', 2, 6000)]
+    cases = [(n, s, p, 6, True) for n, s, p in small]
+    if args.cases == 'all':
+        cases.append(('configPCF_2cm_PTF2', 2, 6000, 6, False))          # real stochastic-depth draws under capture (philox)
+        cases.append(('configPCF_2cm_PTF2', 2, 120000, 5, True))          # the configuration's own size (MAX_POINTS_NUM x BATCH_SIZE)
+    for c in cases:
+        print(json.dumps(run_case(*c, dev)), flush=True)
+        torch.cuda.empty_cache()
+    print(json.dumps({'done': True}), flush=True)
+
+
+if __name__ == '__main__':
+    main()
