@@ -25,8 +25,13 @@ _finish = _sig('pcf_hip_adamw_finish', [_P, _I, _P, _F, _D, _D, _P])
 
 class FusedAdamW(torch.optim.Optimizer):
     """torch.optim.AdamW for float32 parameters on one HIP device, with clip_grad_norm_ folded in:
-    ``step(max_grad_norm=10)`` = ``clip_grad_norm_(params, 10); step()``.  `last_grad_norm` is the (device) total norm
-    of the gradients before clipping."""
+    ``step(max_grad_norm=10)`` = ``clip_grad_norm_(params, 10); step()`` with ONE norm over all parameter groups.
+    `last_grad_norm` is the (device) total norm of the gradients before clipping.
+
+    Step counter: one float32 device counter per parameter group (``state[p]['step']`` of every parameter is a view of
+    it).  Two consequences, both different from torch's per-parameter counters: a parameter that receives its first gradient
+    later than the rest of its group takes the group's bias correction, not its own; and the counter is exact up to
+    2**24 steps (16.7 M -- the reference's schedules run 300 epochs x ~600 iterations)."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         if lr < 0 or eps < 0 or weight_decay < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1:
@@ -62,16 +67,21 @@ class FusedAdamW(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None, max_grad_norm=None):
+        """One AdamW update of every group; with `max_grad_norm` the gradients of ALL groups are first clipped by ONE global
+        2-norm, as ``clip_grad_norm_(model.parameters(), max_norm)`` does (train_ScanNet_DDP_WarmUP.py:421): the squared
+        norms of every group go into one partial buffer, every group's record then gets the same total norm and
+        coefficient, and the updates run per group with the group's own hyper-parameters."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
         nmax, chunk = _max_tensors(), _chunk()
+        work, dev = [], None
         for gi, group in enumerate(self.param_groups):
             ps = [p for p in group['params'] if p.grad is not None]
             if not ps:
                 continue
-            dev = ps[0].device
+            dev = ps[0].device if dev is None else dev
             for p in ps:
                 if p.dtype != torch.float32 or p.grad.dtype != torch.float32 or not p.is_cuda or p.device != dev \
                         or not p.is_contiguous() or p.grad.is_sparse:
@@ -85,26 +95,35 @@ class FusedAdamW(torch.optim.Optimizer):
             rec = self._record(gi, group, dev)
             for p in ps:
                 self.state[p]['step'] = rec[1]                       # one shared device counter (a view of the record)
-            b1, b2 = group['betas']
             lists = [ps[i:i + nmax] for i in range(0, len(ps), nmax)]
             nparts = [sum((p.numel() + chunk - 1) // chunk for p in l) for l in lists]
-            partials = torch.empty(sum(nparts), dtype=torch.float32, device=dev)
-            stream = _stream(dev)
             tables = []
             for l in lists:
                 n = len(l)
                 arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
                 tables.append((n, arr(l), arr([p.grad for p in l]), arr([self.state[p]['exp_avg'] for p in l]),
                                arr([self.state[p]['exp_avg_sq'] for p in l]), (_LL * n)(*[p.numel() for p in l])))
-            with _guard(dev):
-                off = 0
+            work.append((group, rec, tables, nparts))
+        if not work:
+            return loss
+        total = sum(sum(nparts) for _, _, _, nparts in work)
+        partials = torch.empty(total, dtype=torch.float32, device=dev)
+        stream = _stream(dev)
+        with _guard(dev):
+            off = 0
+            for group, rec, tables, nparts in work:          # squared norms of every group into ONE list of partials
+                b1, b2 = group['betas']
                 for (n, pp, gg, mm, vv, cc), k in zip(tables, nparts):
                     _call(_list, 0, n, pp, gg, mm, vv, cc, rec.data_ptr(), partials.data_ptr(), off, b1, b2, group['eps'],
                           group['weight_decay'], stream)
                     off += k
+            for group, rec, tables, nparts in work:          # the same global norm and coefficient into every group's record
+                b1, b2 = group['betas']
                 _call(_finish, partials.data_ptr(), off, rec.data_ptr(), float(max_grad_norm or 0.0), b1, b2, stream)
+            for group, rec, tables, nparts in work:
+                b1, b2 = group['betas']
                 for n, pp, gg, mm, vv, cc in tables:
                     _call(_list, 1, n, pp, gg, mm, vv, cc, rec.data_ptr(), None, 0, b1, b2, group['eps'], group['weight_decay'],
                           stream)
-            self.last_grad_norm = rec[2]
+        self.last_grad_norm = work[0][1][2]
         return loss
