@@ -166,7 +166,12 @@ __global__ __launch_bounds__(BLOCK) void voxel_mean_kernel(const float* __restri
 
 // ---- level-0 voxelisation: one point per occupied voxel (util/voxelize.py:44-82) ----------------------------------
 // key = FNV64-1A over floor(coord / voxel_size) taken as uint64 per axis (:10-22, :58-62).  The division runs in double:
-// numpy promotes the float32 coordinates against the 0-d float64 array np.array(voxel_size) (:58).
+// numpy promotes the float32 coordinates against the 0-d float64 array np.array(voxel_size) (:58) -- under NumPy >= 2
+// (NEP 50), which is what the fixtures were generated with (2.2.6).  Under NumPy 1.x value-based casting keeps a float32
+// array divided by a 0-d float64 array in float32, so points within one float32 rounding of a voxel face can floor
+// differently there: parity for float32 input is pinned for NumPy >= 2 semantics only (the reference's data loader hands
+// float64 coordinates, which divide in double under both).  'deterministic' mode returns the LOWEST point index of a voxel
+// where the reference's unstable argsort returns an arbitrary member.
 __global__ __launch_bounds__(BLOCK) void fnv_key_kernel(const float* __restrict__ pts, int n, double voxel,
                                                         unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals) {
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {

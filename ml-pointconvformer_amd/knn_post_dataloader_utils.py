@@ -261,7 +261,12 @@ def voxelize(coord, voxel_size=0.05, hash_type='fnv', mode='random', seed=None):
     returns the lowest point index of every voxel (the reference returns whichever point its unstable argsort put first);
     'random' one pseudo-random point per voxel (torch's global seed unless `seed` is given); 'multiple' the list of
     index sets that together cover every point.  Only the FNV hash (the reference's default, the one its data loader
-    uses: scannet_data_loader_color_DDP.py:210) is built."""
+    uses: scannet_data_loader_color_DDP.py:210) is built.
+
+    NumPy semantics: the voxel index is floor(coord / voxel_size) with the division in double, which is what NumPy >= 2
+    (NEP 50) computes for float32 coordinates against np.array(voxel_size) and what any NumPy computes for the float64
+    coordinates of the reference's loader.  Under NumPy 1.x float32 input divides in float32 upstream: parity for that
+    combination is not pinned (tests/golden fixtures were made with NumPy 2.2.6)."""
     if hash_type != 'fnv':
         raise NotImplementedError("voxelize: only hash_type='fnv' is built (util/voxelize.py:58-62)")
     pts = _as_device_points(coord)
