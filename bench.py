@@ -751,6 +751,7 @@ def main():
         if quiet is not None:          # warm-up runs on a side stream by design (graph capture rules)
             quiet(False)
         g = torch.cuda.CUDAGraph()
+        tick = torch.zeros(1, dtype=torch.int32, device=dev)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -762,6 +763,7 @@ def main():
             # N > 1: other threads of the process (the collective library's watchdog) may touch the runtime during capture
             mode = {} if world == 1 else {'capture_error_mode': 'thread_local'}
             with torch.cuda.graph(g, **mode):
+                tick.add_(1)          # a trivial first node (pcf_train._graph_preamble: keep the graph's first node off the step's kernels)
                 forward_backward()
                 if bucket is not None:
                     bucket.pack()

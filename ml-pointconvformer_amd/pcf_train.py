@@ -184,6 +184,25 @@ def _training_state(model, optimizer):
     return out
 
 
+_PREAMBLE = {}
+
+
+def _graph_preamble(dev):
+    """First node of every captured graph: one trivial kernel on a persistent 4-byte tensor.  The round-2 replay fault
+    sat at the first work of a relaunched graph (its first node, a memset, had not taken effect before the counting sort
+    behind it; DESIGN.md "graph replay fault").  The library no longer emits memset nodes; this keeps whatever a runtime
+    does to a graph's FIRST node away from the iteration's own kernels as well.  Cost: one ~2 us kernel per replay."""
+    t = _PREAMBLE.get(dev)
+    if t is None:
+        raise RuntimeError('pcf_train: _graph_preamble_init(device) must run before the capture starts')
+    t.add_(1)
+
+
+def _graph_preamble_init(dev):
+    if dev not in _PREAMBLE:
+        _PREAMBLE[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+
+
 _HIP_NODE_KINDS = {0: 'kernel', 1: 'memcpy', 2: 'memset', 3: 'host', 4: 'graph', 5: 'empty', 6: 'wait_event', 7: 'event_record',
                    8: 'ext_semaphore_signal', 9: 'ext_semaphore_wait', 10: 'mem_alloc', 11: 'mem_free'}
 
@@ -244,6 +263,7 @@ class GraphedTrainingStep:
             # call's one optimisation step -- and capture from the state it leaves
             first = training_iteration(self.model, self.optimizer, self.criterion, self.cfg, batch).clone()
             torch.cuda.synchronize()
+        _graph_preamble_init(batch[0].device)
         state = _training_state(self.model, self.optimizer)
         saved = [t.clone() for t in state]
         side = torch.cuda.Stream()
@@ -259,6 +279,7 @@ class GraphedTrainingStep:
         del saved
         g = torch.cuda.CUDAGraph(keep_graph=True) if self.keep_graph else torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, pool=self.pool if self.share_pool else None):
+            _graph_preamble(batch[0].device)
             loss = training_iteration(self.model, self.optimizer, self.criterion, self.cfg, batch)
         if self.share_pool and self.pool is None:
             self.pool = g.pool()
@@ -338,6 +359,7 @@ class DataParallelStep:
         if not self.optimizer.state:          # fresh optimizer: its first step is taken eagerly (this call's one step)
             first = self.eager(batch).clone()
             torch.cuda.synchronize()
+        _graph_preamble_init(dev)
         state = _training_state(self.model, self.optimizer)
         saved = [t.clone() for t in state]
         side = torch.cuda.Stream()
@@ -356,10 +378,12 @@ class DataParallelStep:
             # other threads of the process (the collective library's watchdog) may touch the runtime during capture
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                _graph_preamble(dev)
                 loss = self._half1(batch)
             if gb is None:
                 gb = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gb, capture_error_mode='thread_local'):
+                    _graph_preamble(dev)
                     self._half2()
         except Exception as exc:          # capture is an optimisation of the host side, not a requirement
             ok = False
