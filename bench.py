@@ -357,8 +357,15 @@ def bench_train(args):
         args.scenes = cfg.scenes
     torch.manual_seed(1)
     net = pcf_model.PointConvFormer_Segmentation(cfg).to(dev).train()
+    sync_bn = bool(args.sync_bn) and world > 1
+    if sync_bn:
+        # the reference's YAMLs set sync_bn: True and the script converts the model (train_ScanNet_DDP_WarmUP.py:192-193):
+        # batch statistics over all ranks.  This build then takes every BatchNorm out of the fused chains
+        # (pcf_fused.cross_rank_bn) and runs the collectives of pcf_fused.sync_bn_act inside the forward, which a HIP
+        # graph cannot hold: eager halves.  Default: per-rank statistics (sync_bn False), fused chains, replay.
+        net = torch.nn.SyncBatchNorm.convert_sync_batchnorm(net)
     use_ddp = world > 1 and args.ddp
-    use_graph = not args.no_graph and not use_ddp
+    use_graph = not args.no_graph and not use_ddp and not sync_bn
     opt = pcf_train.make_optimizer(cfg, net, capturable=use_graph)
     crit = torch.nn.CrossEntropyLoss(ignore_index=cfg.ignore_label, label_smoothing=cfg.label_smoothing).to(dev)
     # a small pool of distinct packed batches, rotated, so the kNN / CSR work is real every step
@@ -470,7 +477,7 @@ def bench_train(args):
                                    f'{args.scenes} scenes x ~{args.points} points per GPU per iteration '
                                    f'({n_pts} level-0 points, levels {pool[0][4]}), kNN + CSR + fwd + bwd + AdamW',
                        'parallelism': f'dp{world}',
-                       'sync_bn': False}}
+                       'sync_bn': sync_bn}}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line['cpu_baseline'] = cpu_baseline_train(cfg, net, min(args.points, 8000))
@@ -654,6 +661,9 @@ def main():
     ap.add_argument('--graph', action='store_true',
                     help='insist on HIP-graph replay (a failed capture is an error instead of a fall-back; with N > 1 GPUs '
                          'the replay-versus-eager trial is skipped)')
+    ap.add_argument('--sync-bn', action='store_true',
+                    help='train workload, N > 1: convert the model to SyncBatchNorm as the reference does with sync_bn: True '
+                         '(cross-rank statistics; BatchNorms leave the fused chains, eager halves)')
     ap.add_argument('--ddp', action='store_true',
                     help='N > 1: eager steps under torch DistributedDataParallel instead of the flat gradient bucket')
     ap.add_argument('--deterministic', action='store_true',
