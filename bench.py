@@ -674,7 +674,10 @@ def main():
         return bench_train(args)
     train_extra = None
     if args.workload == 'layer' and args.gpus == 1 and 'WORLD_SIZE' not in os.environ and not args.no_train:
-        train_extra = train_in_child(args)          # before this process touches the GPU
+        try:
+            train_extra = train_in_child(args)          # before this process touches the GPU
+        except Exception as exc:
+            train_extra = {'error': f'{type(exc).__name__}: {exc}'}
     if args.points is None:
         args.points = N_POINTS if args.workload == 'layer' else 40000
     if args.scenes is None:
