@@ -483,7 +483,7 @@ def bench_train(args):
                 line['cpu_baseline'] = cpu_baseline_train(cfg, net, min(args.points, 8000))
             except Exception as exc:          # the baseline is a reported aside; the GPU number stands without it
                 line['cpu_baseline'] = {'error': f'{type(exc).__name__}: {exc}'}
-        print(json.dumps(line), flush=True)
+        print(json.dumps(_json_safe(line)), flush=True)
     pcf_dist.shutdown()
 
 
@@ -544,7 +544,7 @@ def bench_subsample(args):
     if not args.no_cpu_baseline:
         line['cpu_baseline'] = cpu_baseline_subsample([s['xyz'].cpu().numpy() for s in scenes],
                                                       [s['nrm'].cpu().numpy() for s in scenes], grid, n0)
-    print(json.dumps(line), flush=True)
+    print(json.dumps(_json_safe(line)), flush=True)
     pcf_dist.shutdown()
 
 
@@ -577,6 +577,18 @@ def cpu_baseline_subsample(xyzs, nrms, grid, n0, iters=5):
             'sample': f'full workload ({len(xyzs)} scenes, {n0} level-0 points, 4 levels), 1 warm-up + {iters} timed runs, '
                       f'median {med * 1e3:.1f} ms; grid_subsampling.cpp:9-110 compiled from the reference sources'
                       if kind == 'reference' else f'full workload, numpy restatement, median {med * 1e3:.1f} ms'}
+
+
+def _json_safe(obj):
+    """The one output line must parse as strict JSON: non-finite floats (a NaN loss, an error ratio against an all-zero
+    tensor) become null."""
+    if isinstance(obj, float):
+        return obj if obj == obj and abs(obj) != float('inf') else None
+    if isinstance(obj, dict):
+        return {k: _json_safe(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return [_json_safe(v) for v in obj]
+    return obj
 
 
 def self_launch(args):
@@ -955,7 +967,7 @@ def main():
                 line['parity'] = {'error': f'{type(exc).__name__}: {exc}'}
                 line['cpu_baseline'] = cpu_baseline(layer.state_dict(), xyz, nrm, feats.detach(), idx)
             line['cpu_baseline_pointconv_single'] = cpu_baseline_pointconv()
-        print(json.dumps(line), flush=True)
+        print(json.dumps(_json_safe(line)), flush=True)
     pcf_dist.shutdown()
 
 

@@ -59,3 +59,40 @@ def test_cpu_baseline_train_runs_the_oracle_model():
     net = pcf_model.PointConvFormer_Segmentation(cfg).train()
     rec = bench.cpu_baseline_train(cfg, net, 1200)
     assert rec['kind'] == 'port' and rec['value'] > 0 and rec['unit'] == 'level-0 points/s' and 'oracle/pcf_oracle.py' in rec['sample']
+
+
+def test_layer_workload_glue_code_runs_end_to_end_without_a_gpu():
+    """tools/bench_dry_run.py: bench.py's main() for the headline workload with no-op launches and dummy stream / graph /
+    event objects -- every line of the timing loops, HIP-event bookkeeping, roofline blocks, profile evidence, parity block
+    and JSON assembly executes and the output parses as strict JSON with the contract's keys."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'bench_dry_run.py'), '--points', '1500', '--steps', '2',
+                          '--warmup', '1', '--no-train'], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = json.loads(res.stdout.strip().splitlines()[-1], parse_constant=lambda c: (_ for _ in ()).throw(ValueError(c)))
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+                'dtype', 'data', 'config', 'roofline', 'cpu_baseline', 'parity', 'parity_max_rel_err'):
+        assert key in line, key
+    assert line['config']['workload'].startswith('PCFLayer(64->64') and line['dtype'] == 'f32' and line['n_gpus'] == 1
+    assert {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'} <= set(line['roofline'])
+    assert {'value', 'unit', 'cores', 'kind', 'sample'} <= set(line['cpu_baseline'])
+
+
+def test_train_workload_glue_code_runs_end_to_end_without_a_gpu():
+    """bench.py --workload train through tools/bench_dry_run.py: model build, eager iterations, GraphedTrainingStep (state
+    snapshot, warm-up, capture, replay -- with dummy graph objects), timing, the oracle's model iteration as CPU baseline,
+    JSON assembly; strict JSON (a NaN loss becomes null)."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'bench_dry_run.py'), '--workload', 'train', '--model',
+                          'configPCF_2cm_PTF2', '--points', '1000', '--scenes', '2', '--steps', '2', '--warmup', '1'],
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = json.loads(res.stdout.strip().splitlines()[-1], parse_constant=lambda c: (_ for _ in ()).throw(ValueError(c)))
+    assert line['hip_graph'] is True and line['step_path'].startswith('HIP-graph replay') and line['eager_ms_per_step'] > 0
+    assert line['cpu_baseline']['kind'] == 'port' and line['config']['sync_bn'] is False

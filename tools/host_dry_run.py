@@ -105,6 +105,8 @@ def main():
     ap.add_argument('--iters', type=int, default=5)
     ap.add_argument('--profile', action='store_true')
     ap.add_argument('--top', type=int, default=35)
+    ap.add_argument('--no-opt', action='store_true', help='forward + backward only (the CPU optimizer is not what the GPU path runs)')
+    ap.add_argument('--sort', default='tottime')
     ap.add_argument('--dp', action='store_true', help="the iteration as pcf_train.DataParallelStep's eager halves (one process)")
     args = ap.parse_args()
     torch.set_num_threads(1)
@@ -126,6 +128,10 @@ def main():
     def step():
         if args.dp:
             return dp(batch)
+        if args.no_opt:
+            loss = pcf_train.forward_backward(net, crit, cfg, batch)
+            opt.zero_grad(set_to_none=True)
+            return loss
         return pcf_train.training_iteration(net, opt, crit, cfg, batch)
 
     step()                                           # first call: lazy module state
@@ -145,7 +151,7 @@ def main():
     print('most frequent entry points per iteration:', [(k.replace('pcf_hip_', ''), v // args.iters) for k, v in top])
     if prof:
         st = pstats.Stats(prof)
-        st.sort_stats('tottime').print_stats(args.top)
+        st.sort_stats(args.sort).print_stats(args.top)
 
 
 if __name__ == '__main__':
