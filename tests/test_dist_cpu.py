@@ -368,3 +368,37 @@ def test_data_parallel_step_equals_ddp_two_ranks():
             assert abs(la - lb) < 1e-5 * max(1.0, abs(la)), (rank, losses)
         assert diff < 2e-5 * max(1.0, scale), (rank, diff, scale)
         assert bdiff < 1e-5, (rank, bdiff)
+
+
+def _bench_dry_run_two_ranks(extra):
+    """bench.py under `python -m torch.distributed.run --nproc-per-node 2` with tools/bench_dry_run.py's stubs: no-op
+    launches, dummy graph / stream objects, REAL ranks and collectives over gloo."""
+    import json
+    import subprocess
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'tools', 'bench_dry_run.py'), '--gpus', '2', '--steps', '2',
+           '--warmup', '1'] + extra
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=500)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, 'rank 0 prints exactly one JSON line'
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(600)
+def test_bench_train_workload_two_ranks_control_flow():
+    """The N > 1 train path of bench.py end to end on two gloo ranks (kernels stubbed): parameter broadcast, DataParallelStep
+    captures on both ranks, the capture agreement, the replay-versus-eager trial, the timed loop with one all-reduce per step,
+    max-over-ranks timing -- no deadlock, one JSON line, whole-job keys."""
+    line = _bench_dry_run_two_ranks(['--workload', 'train', '--model', 'configPCF_10cm_lite', '--points', '700', '--scenes', '2'])
+    assert line['n_gpus'] == 2 and line['world_size'] == 2 and line['collective_backend'] == 'gloo'
+    assert line['grad_sync'].startswith('one flat-bucket all-reduce') and line['config']['parallelism'] == 'dp2'
+    assert line['scaling'] == 'weak' and line['config']['sync_bn'] is False
+
+
+@pytest.mark.timeout(600)
+def test_bench_layer_workload_two_ranks_control_flow():
+    """The N > 1 layer path (HIP-graph replay + flat bucket + trial, or eager) on two gloo ranks with stubbed kernels."""
+    line = _bench_dry_run_two_ranks(['--points', '1200'])
+    assert line['n_gpus'] == 2 and line['grad_sync'] == 'one flat-bucket all-reduce per step'
+    assert line['value'] > 0 and 'roofline' in line

@@ -70,8 +70,19 @@ def main():
     torch.cuda.graph = lambda g, **k: contextlib.nullcontext()
     torch.cuda.Event = FakeEvent
     torch.cuda.is_current_stream_capturing = lambda: False
-    pcf_dist.setup = lambda backend=None: (0, 1, 0, cpu)
-    pcf_dist.fence = lambda dev=None: None
+    if 'WORLD_SIZE' in os.environ:          # under torch.distributed.run: real ranks and real collectives, over gloo
+        real_setup = pcf_dist.setup
+        torch.cuda.set_device = lambda *a, **k: None
+
+        def setup(backend=None):
+            rank, world, local_rank = pcf_dist.env_rank()
+            if not torch.distributed.is_initialized():
+                torch.distributed.init_process_group('gloo', rank=rank, world_size=world)
+            return rank, world, local_rank, cpu
+        pcf_dist.setup = setup
+    else:
+        pcf_dist.setup = lambda backend=None: (0, 1, 0, cpu)
+        pcf_dist.fence = lambda dev=None: None
     if 'train' in sys.argv:
         # scenes and their levels come from GPU kernels (voxelisation, grid subsampling) whose outputs drive host code:
         # use the oracle-made batch of host_dry_run instead
