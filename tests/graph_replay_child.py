@@ -57,7 +57,7 @@ def run_case(name, scenes, points, calls, freeze_draws, dev):
     pg = torch.cat([p.detach().reshape(-1) for p in nets[1].parameters()])
     de, dg = (pe - start).double(), (pg - start).double()
     nbt = [[int(b) for n, b in net.named_buffers() if n.endswith('num_batches_tracked')] for net in nets]
-    steps = [float(o._recs[0][0][1]) for o in opts]
+    steps = [float(o.state[o.param_groups[0]['params'][0]]['step']) for o in opts]          # FusedAdamW: a view of its device record
     return {'case': name, 'scenes': scenes, 'points': points, 'levels': pool[0][4], 'eager_losses': eager, 'graph_losses': graphed,
             'node_kinds': kinds, 'update_cosine': float((de @ dg) / (de.norm() * dg.norm() + 1e-30)),
             'finite': bool(torch.isfinite(pg).all()), 'num_batches_tracked': [[min(v), max(v)] for v in nbt],
@@ -68,7 +68,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--cases', default='small')
     args = ap.parse_args()
-    dev = torch.device('cuda:0')
+    dev = torch.device(os.environ.get('PCF_TEST_DEVICE', 'cuda:0'))          # tools/dry_env.py runs this on the CPU
     small = [('configPCF_10cm_lite', 2, 3000), ('configPCF_10cm', 2, 3000), ('configPCF_5cm', 1, 6000),
              ('configPCF_2cm_PTF2', 2, 6000)]
     cases = [(n, s, p, 6, True) for n, s, p in small]

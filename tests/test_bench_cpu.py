@@ -96,3 +96,22 @@ def test_train_workload_glue_code_runs_end_to_end_without_a_gpu():
     line = json.loads(res.stdout.strip().splitlines()[-1], parse_constant=lambda c: (_ for _ in ()).throw(ValueError(c)))
     assert line['hip_graph'] is True and line['step_path'].startswith('HIP-graph replay') and line['eager_ms_per_step'] > 0
     assert line['cpu_baseline']['kind'] == 'port' and line['config']['sync_bn'] is False
+
+
+def test_graph_replay_child_control_flow_without_a_gpu():
+    """tests/graph_replay_child.py (the body of the GPU replay test) through tools/dry_env.py: all four model YAMLs, eager
+    iterations and GraphedTrainingStep calls with stubbed launches and dummy graphs.  In the dry environment a "capture"
+    executes its body and a "replay" does nothing, so after six calls the graph path has taken exactly three real steps
+    (the eager first step + two capture bodies): the warm-up iterations of both captures were rolled back."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'dry_env.py'), os.path.join(ROOT, 'tests', 'graph_replay_child.py'),
+                          '--cases', 'small'], capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    recs = [json.loads(l) for l in res.stdout.splitlines() if l.startswith('{')]
+    cases = [r for r in recs if 'case' in r]
+    assert recs[-1] == {'done': True} and len(cases) == 4
+    for r in cases:
+        assert r['optimizer_steps'] == [6.0, 3.0] and r['num_batches_tracked'] == [[6, 6], [3, 3]], r
