@@ -357,6 +357,10 @@ int pcf_hip_grid_subsample(const float* points, const float* features, const int
 size_t pcf_hip_voxelize_workspace_bytes(int n_points);
 int pcf_hip_voxelize(const float* points, int n_points, double voxel_size, int mode, unsigned long long seed, int rank,
                      int64_t* out_index, int32_t* out_total, void* workspace, size_t workspace_bytes, void* stream);
+/* The same for float64 coordinates (a loader that keeps its coordinates in double: the quotient is then taken on the double
+ * values themselves, as numpy does for float64 input under any version -- not on their float32 roundings). */
+int pcf_hip_voxelize_f64(const double* points, int n_points, double voxel_size, int mode, unsigned long long seed, int rank,
+                     int64_t* out_index, int32_t* out_total, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- per-edge helpers around the aggregate ---------------------------------------------------
  * replace index_points (layer_utils.py:13-30) and its index_put_ backward: */

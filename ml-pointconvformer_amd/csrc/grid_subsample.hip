@@ -172,7 +172,10 @@ __global__ __launch_bounds__(BLOCK) void voxel_mean_kernel(const float* __restri
 // differently there: parity for float32 input is pinned for NumPy >= 2 semantics only (the reference's data loader hands
 // float64 coordinates, which divide in double under both).  'deterministic' mode returns the LOWEST point index of a voxel
 // where the reference's unstable argsort returns an arbitrary member.
-__global__ __launch_bounds__(BLOCK) void fnv_key_kernel(const float* __restrict__ pts, int n, double voxel,
+// T = float (promoted to double before the division, above) or double (coordinates handed over in float64: the quotient
+// numpy computes under any version).
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void fnv_key_kernel(const T* __restrict__ pts, int n, double voxel,
                                                         unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals) {
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
         unsigned long long h = 14695981039346656037ull;
@@ -308,8 +311,8 @@ size_t pcf_hip_voxelize_workspace_bytes(int n_points) {
     return pcf::sub_plan(n_points, 1).bytes;
 }
 
-int pcf_hip_voxelize(const float* points, int n_points, double voxel_size, int mode, unsigned long long seed, int rank,
-                     int64_t* out_index, int32_t* out_total, void* workspace, size_t workspace_bytes, void* stream) {
+static int voxelize_impl(const void* points, bool f64, int n_points, double voxel_size, int mode, unsigned long long seed, int rank,
+                         int64_t* out_index, int32_t* out_total, void* workspace, size_t workspace_bytes, void* stream) {
     using namespace pcf;
     PCF_REQUIRE(n_points >= 0 && voxel_size > 0.0 && mode >= 0 && mode <= 2 && rank >= 0, "voxelize: bad arguments (n=%d voxel=%g mode=%d)",
                 n_points, voxel_size, mode);
@@ -331,7 +334,8 @@ int pcf_hip_voxelize(const float* points, int n_points, double voxel_size, int m
     int32_t* start = reinterpret_cast<int32_t*>(ws + w.off_start);
     const int n = n_points;
     const int pgrid = std::max(1, std::min(ceil_div(n, BLOCK), 4096));
-    hipLaunchKernelGGL(fnv_key_kernel, dim3(pgrid), dim3(BLOCK), 0, s, points, n, voxel_size, keys_a, vals_a);
+    if (f64) hipLaunchKernelGGL(fnv_key_kernel<double>, dim3(pgrid), dim3(BLOCK), 0, s, static_cast<const double*>(points), n, voxel_size, keys_a, vals_a);
+    else hipLaunchKernelGGL(fnv_key_kernel<float>, dim3(pgrid), dim3(BLOCK), 0, s, static_cast<const float*>(points), n, voxel_size, keys_a, vals_a);
     if (int e = check_launch("voxelize: keys")) return e;
     size_t sb = w.sort_bytes;
     if (rocprim::radix_sort_pairs(ws + w.off_sort, sb, (const unsigned long long*)keys_a, keys_b, (const uint32_t*)vals_a, vals_b,
@@ -342,6 +346,16 @@ int pcf_hip_voxelize(const float* points, int n_points, double voxel_size, int m
     hipLaunchKernelGGL(vox_start_kernel, dim3(pgrid), dim3(BLOCK), 0, s, keys_b, vid, n, start, out_total);
     hipLaunchKernelGGL(vox_pick_kernel, dim3(pgrid), dim3(BLOCK), 0, s, vals_b, start, out_total, n, mode, seed, rank, out_index);
     return check_launch("voxelize: pick");
+}
+
+int pcf_hip_voxelize(const float* points, int n_points, double voxel_size, int mode, unsigned long long seed, int rank,
+                     int64_t* out_index, int32_t* out_total, void* workspace, size_t workspace_bytes, void* stream) {
+    return voxelize_impl(points, false, n_points, voxel_size, mode, seed, rank, out_index, out_total, workspace, workspace_bytes, stream);
+}
+
+int pcf_hip_voxelize_f64(const double* points, int n_points, double voxel_size, int mode, unsigned long long seed, int rank,
+                         int64_t* out_index, int32_t* out_total, void* workspace, size_t workspace_bytes, void* stream) {
+    return voxelize_impl(points, true, n_points, voxel_size, mode, seed, rank, out_index, out_total, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -269,7 +269,13 @@ def voxelize(coord, voxel_size=0.05, hash_type='fnv', mode='random', seed=None):
     combination is not pinned (tests/golden fixtures were made with NumPy 2.2.6)."""
     if hash_type != 'fnv':
         raise NotImplementedError("voxelize: only hash_type='fnv' is built (util/voxelize.py:58-62)")
-    pts = _as_device_points(coord)
+    if isinstance(coord, np.ndarray) and coord.dtype == np.float64 or isinstance(coord, torch.Tensor) and coord.dtype == torch.float64:
+        # float64 coordinates (what np.floor(coord / voxel_size) sees upstream when the loader keeps doubles): hashed from the
+        # double values, not from their float32 roundings
+        pts = torch.as_tensor(coord).to(_device() if not (isinstance(coord, torch.Tensor) and coord.is_cuda) else coord.device)
+        pts = pts.reshape(-1, 3).contiguous()
+    else:
+        pts = _as_device_points(coord)
     if mode == 'deterministic':
         return pcf_cuda.voxelize(pts, voxel_size, 'deterministic')[0]
     if mode == 'multiple':

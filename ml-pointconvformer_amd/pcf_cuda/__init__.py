@@ -80,6 +80,7 @@ _gridsub_ws = _sig('pcf_hip_grid_subsample_workspace_bytes', [_I, _I], _Z)
 _gridsub = _sig('pcf_hip_grid_subsample', [_P, _P, _P, _I, _I, _I, ctypes.c_float, _P, _P, _P, _P, _P, _Z, _P])
 _vox_ws = _sig('pcf_hip_voxelize_workspace_bytes', [_I], _Z)
 _vox = _sig('pcf_hip_voxelize', [_P, _I, ctypes.c_double, _I, ctypes.c_ulonglong, _I, _P, _P, _P, _Z, _P])
+_vox_f64 = _sig('pcf_hip_voxelize_f64', [_P, _I, ctypes.c_double, _I, ctypes.c_ulonglong, _I, _P, _P, _P, _Z, _P])
 _knn_grid = _sig('pcf_hip_knn_grid', [_P] * 4 + [_I] * 4 + [_P, _P, _Z, _P])
 _knn_wave = _sig('pcf_hip_knn_wave', [_P] * 4 + [_I] * 3 + [_P] * 2)
 _gemm_nt = _sig('pcf_hip_gemm_nt', [_P] * 4 + [_I] * 3 + [_P])
@@ -560,8 +561,10 @@ def voxelize(points, voxel_size, mode='deterministic', seed=0, rank=0):
     """At most one point per occupied voxel (util/voxelize.py:44-82 on the GPU, FNV hash).  points [N,3] f32 device
     tensor of ONE cloud -> (idx int64 [V] in ascending key order, fullest-voxel count).  mode 'deterministic': the voxel's
     lowest point index; 'random': a pseudo-random point of the voxel from `seed`; 'rank': point `rank` mod count.  Reading
-    V back is the one device->host sync (data-dependent output size)."""
-    _floats(points=points)
+    V back is the one device->host sync (data-dependent output size).  float64 points are hashed from their double values
+    (pcf_hip_voxelize_f64), as numpy does for a float64 coordinate array."""
+    f64 = isinstance(points, torch.Tensor) and points.dtype == torch.float64
+    _check_input(points, 'points', torch.float64 if f64 else torch.float32)
     if points.dim() != 2 or points.shape[1] != 3:
         raise RuntimeError('pcf_cuda: points must be [n,3]')
     n = points.shape[0]
@@ -571,7 +574,7 @@ def voxelize(points, voxel_size, mode='deterministic', seed=0, rank=0):
     with _guard(dev):
         nbytes = _vox_ws(n)
         ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=dev)
-        _call(_vox, _ptr(points), n, float(voxel_size), _VOX_MODES[mode], int(seed) & (2 ** 64 - 1), int(rank), out.data_ptr(),
+        _call(_vox_f64 if f64 else _vox, _ptr(points), n, float(voxel_size), _VOX_MODES[mode], int(seed) & (2 ** 64 - 1), int(rank), out.data_ptr(),
               meta.data_ptr(), ws.data_ptr(), nbytes, _stream(dev))
     total, longest = meta.cpu().tolist()
     return out[:total], longest

@@ -15,7 +15,10 @@ FNV_PRIME = np.uint64(1099511628211)
 def fnv_keys(coord, voxel_size):
     """uint64 [N]: hash of floor(coord / voxel_size) per axis, the quotient in float64 (numpy promotes the float32
     coordinates against the 0-d float64 array np.array(voxel_size), util/voxelize.py:58)."""
-    d = np.floor(np.asarray(coord, np.float32).astype(np.float64) / np.float64(voxel_size))
+    coord = np.asarray(coord)
+    if coord.dtype != np.float64:                          # float64 input: the quotient of the doubles themselves (any numpy)
+        coord = coord.astype(np.float32).astype(np.float64)
+    d = np.floor(coord / np.float64(voxel_size))
     a = d.astype(np.int64).astype(np.uint64)              # two's complement of negative whole numbers
     h = np.full(a.shape[0], FNV_OFFSET, np.uint64)
     with np.errstate(over='ignore'):

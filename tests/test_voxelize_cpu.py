@@ -8,7 +8,7 @@ import pytest
 from conftest import GOLDEN
 from oracle import voxelize_oracle as V
 
-CASES = ['vox_surface', 'vox_dense', 'vox_negative', 'vox_2cm', 'vox_single']
+CASES = ['vox_surface', 'vox_dense', 'vox_negative', 'vox_2cm', 'vox_single', 'vox_f64_faces']
 
 
 def load(name):
@@ -44,3 +44,14 @@ def test_multiple_mode_sets():
         assert np.array_equal(g['key'][idx], g['key'][g[f'multi{r}']])      # same voxel sequence as the reference's set r
         seen.update(idx.tolist())
     assert len(seen) == g['coord'].shape[0]                                    # together they cover every point
+
+
+def test_float64_coordinates_are_hashed_as_doubles():
+    """vox_f64_faces: float64 coordinates within 1e-9 .. 1e-12 of voxel faces.  The reference divides the doubles
+    themselves (any NumPy); hashing their float32 roundings would move thousands of these points into a neighbouring voxel --
+    which is why the library has a float64 entry point (pcf_hip_voxelize_f64) instead of casting on the way in."""
+    g = load('vox_f64_faces')
+    assert g['coord'].dtype == np.float64
+    assert np.array_equal(V.fnv_keys(g['coord'], float(g['voxel'])), g['key'])
+    rounded = V.fnv_keys(g['coord'].astype(np.float32), float(g['voxel']))
+    assert (rounded != g['key']).sum() > 1000

@@ -171,3 +171,22 @@ def test_fused_adamw_two_groups_one_global_clip(device):
             torch.testing.assert_close(x.grad, y.grad, rtol=2e-6, atol=1e-9)
             torch.testing.assert_close(opt.state[x]['exp_avg'], want.state[y]['exp_avg'], rtol=2e-6, atol=1e-8)
         assert float(opt.state[ma[0]]['step']) == it + 1 and float(opt.state[mb[0]]['step']) == it + 1
+
+
+def test_voxelize_float64_coordinates(device):
+    """pcf_hip_voxelize_f64 (round 3): float64 coordinates near voxel faces are hashed from their double values -- bit-exact
+    against the oracle and the reference's voxel sequence (tests/golden/make_voxelize_f64_golden.py); the float32 entry point
+    on the rounded coordinates gives a different, equally self-consistent, answer."""
+    import numpy as np
+    import knn_post_dataloader_utils as U
+    from conftest import GOLDEN
+    from oracle import voxelize_oracle as V
+    z = np.load(os.path.join(GOLDEN, 'vox_f64_faces.npz'), allow_pickle=False)
+    coord, vs, key, ref_idx = z['coord'], float(z['voxel']), z['key'], z['idx']
+    assert coord.dtype == np.float64
+    idx = U.voxelize(coord, vs, mode='deterministic').cpu().numpy()
+    want, _ = V.voxelize(coord, vs)
+    assert np.array_equal(idx, want)
+    assert np.array_equal(key[idx], key[ref_idx])
+    idx32 = U.voxelize(coord.astype(np.float32), vs, mode='deterministic').cpu().numpy()
+    assert np.array_equal(idx32, V.voxelize(coord.astype(np.float32), vs)[0]) and not np.array_equal(idx32, idx)
