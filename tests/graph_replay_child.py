@@ -64,6 +64,60 @@ def run_case(name, scenes, points, calls, freeze_draws, dev):
             'optimizer_steps': steps, 'frozen_draws': bool(freeze_draws)}
 
 
+def run_tables_case(name, scenes, points, rounds, dev):
+    """The neighbour tables and the CSR of a captured iteration, kept alive and compared after every replay with tables
+    built eagerly from the same batch: the direct check of the round-2 failure (an uncleared cell histogram / CSR counter on
+    relaunch gives wrong tables long before it gives a fault).  Two graphs, replayed alternately."""
+    import pcf_model
+    import pcf_train
+    cfg = pcf_train.baseline_config(name)
+    crit = torch.nn.CrossEntropyLoss(ignore_index=cfg.ignore_label, label_smoothing=cfg.label_smoothing).to(dev)
+    pool = []
+    for b in range(2):
+        sc = [pcf_train.synthetic_scene(points, cfg.grid_size, seed=9000 + 10 * b + i, device=dev) for i in range(scenes)]
+        pool.append(pcf_train.pack_batch(sc, cfg.grid_size))
+    torch.manual_seed(13)
+    net = pcf_model.PointConvFormer_Segmentation(cfg).to(dev).train()
+    opt = pcf_train.make_optimizer(cfg, net, capturable=True)
+    for batch in pool:
+        pcf_train.training_iteration(net, opt, crit, cfg, batch)
+    torch.cuda.synchronize()
+    graphs = []
+    for batch in pool:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            pcf_train.training_iteration(net, opt, crit, cfg, batch)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            edges = pcf_train.build_edges(cfg, batch[1], batch[4])
+            pcf_train.training_iteration(net, opt, crit, cfg, batch, edges)
+        graphs.append((g, edges, batch))
+    wrong, compared = [], 0
+    for r in range(rounds):
+        for gi, (g, edges, batch) in enumerate(graphs):
+            g.replay()
+            torch.cuda.synchronize()
+            es, ef, ep, inv = edges
+            res, rf, rp, rinv = pcf_train.build_edges(cfg, batch[1], batch[4])
+            for tag, got, want in (('self', es, res), ('forward', ef, rf), ('propagate', ep, rp)):
+                for l, (a, b) in enumerate(zip(got, want)):
+                    compared += 1
+                    if not torch.equal(a, b):
+                        wrong.append(f'round {r} graph {gi} {tag}[{l}]: {int((a != b).any(-1).sum())} rows')
+            for rel in range(3):
+                for part in range(3):
+                    for l, (a, b) in enumerate(zip(inv[rel][part], rinv[rel][part])):
+                        compared += 1
+                        if not torch.equal(a, b):
+                            wrong.append(f'round {r} graph {gi} csr{rel}.{part}[{l}]')
+            print(json.dumps({'progress': name + ' tables', 'round': r, 'graph': gi, 'wrong_so_far': len(wrong)}), flush=True)
+    return {'tables_case': name, 'scenes': scenes, 'points': points, 'levels': pool[0][4], 'compared': compared, 'wrong': wrong[:20],
+            'n_wrong': len(wrong)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--cases', default='small')
@@ -75,6 +129,10 @@ def main():
     if args.cases == 'all':
         cases.append(('configPCF_2cm_PTF2', 2, 6000, 6, False))          # real stochastic-depth draws under capture (philox)
         cases.append(('configPCF_2cm_PTF2', 2, 120000, 5, True))          # the configuration's own size (MAX_POINTS_NUM x BATCH_SIZE)
+    # first the sharpest and cheapest check: tables of replayed iterations against eager ones (no fault even if they differ)
+    for name, sc, pts in (('configPCF_2cm_PTF2', 2, 6000), ('configPCF_10cm', 2, 6000)):
+        print(json.dumps(run_tables_case(name, sc, pts, 3, dev)), flush=True)
+        torch.cuda.empty_cache()
     for c in cases:
         print(json.dumps(run_case(*c, dev)), flush=True)
         torch.cuda.empty_cache()

@@ -34,6 +34,10 @@ def _run_child(cases, timeout):
     tail = '\n'.join(res.stdout.splitlines()[-6:]) + '\n--- stderr ---\n' + res.stderr[-1500:]
     assert res.returncode == 0, f'child exited with {res.returncode} (negative / 134 = aborted, e.g. by a GPU fault):\n{tail}'
     assert recs and recs[-1].get('done'), tail
+    tables = [r for r in recs if 'tables_case' in r]
+    assert len(tables) == 2, tail
+    for t in tables:          # neighbour tables and CSR of every replay bit-identical to eagerly built ones
+        assert t['n_wrong'] == 0 and t['compared'] >= 6 * 22, (t['tables_case'], t['wrong'])
     return [r for r in recs if 'case' in r]
 
 
