@@ -775,7 +775,7 @@ def main():
         quiet = getattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch', None)
         if quiet is not None:          # warm-up runs on a side stream by design (graph capture rules)
             quiet(False)
-        g = torch.cuda.CUDAGraph()
+        g = torch.cuda.CUDAGraph(keep_graph=True)          # the hipGraph_t stays readable: node kinds are reported below
         tick = torch.zeros(1, dtype=torch.int32, device=dev)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -877,6 +877,13 @@ def main():
     fence()
     eager_ms = pcf_dist.max_over_ranks(time.perf_counter() - t0, dev) / args.steps * 1e3
 
+    graph_nodes = None
+    if graph is not None:
+        try:          # node kinds of the replayed step: kernels only (the library clears buffers with its own kernels)
+            import pcf_train
+            graph_nodes = pcf_train.graph_node_counts(graph)
+        except Exception as exc:
+            graph_nodes = {'error': f'{type(exc).__name__}: {exc}'}
     if rank == 0:
         Ci = C_FEAT // 4
         fwd_b, bwd_b = _agg_bytes(Ci, C_MID, HEADS, K_NEI)
@@ -940,7 +947,7 @@ def main():
             'hip_ms_per_entry_point_per_step': {k: round(v, 4) for k, v in sorted(per_step.items())},
             'hip_ms_per_step': round(hip_total_ms, 4),
             'eager_ms_per_step': round(eager_ms, 4),
-            'knn_ms': round(knn_ms, 3), 'csr_ms': round(csr_ms, 3), 'hip_graph': graph is not None,
+            'knn_ms': round(knn_ms, 3), 'csr_ms': round(csr_ms, 3), 'hip_graph': graph is not None, 'graph_nodes': graph_nodes,
             'step_path': ('HIP-graph replay' if graph is not None else 'eager launches') +
                          ('' if world == 1 else (' + one flat-bucket RCCL all-reduce per step' if bucket is not None
                                                  else ' under DistributedDataParallel')),
