@@ -629,9 +629,9 @@ def train_in_child(args):
         cmd.append('--no-cpu-baseline')
     t0 = time.perf_counter()
     try:
-        res = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=480)
     except subprocess.TimeoutExpired:
-        return {'error': 'train child: no result within 900 s'}
+        return {'error': 'train child: no result within 480 s'}
     rec = None
     for l in res.stdout.splitlines():
         if l.startswith('{'):
