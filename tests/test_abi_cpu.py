@@ -92,3 +92,15 @@ def test_zero_kernel_indexing_on_host():
                 lib.pcf_hip_zero_host(ctypes.c_void_p(base + start), n, blocks)
                 assert not buf[start:start + n].any(), (blocks, n, shift)
                 assert (buf[:start] == 0xAB).all() and (buf[start + n:] == 0xAB).all(), (blocks, n, shift)
+
+
+def test_public_header_is_plain_c():
+    """include/pcf_hip.h is the drop-in boundary: it must compile on its own as C99 and as C++ (no torch, no HIP types)."""
+    import shutil
+    import subprocess
+    header = os.path.join(ROOT, 'include', 'pcf_hip.h')
+    for cc, lang in (('gcc', ['-x', 'c', '-std=c99']), ('g++', ['-x', 'c++'])):
+        if shutil.which(cc) is None:
+            pytest.skip(f'no {cc} in this image')
+        res = subprocess.run([cc, '-fsyntax-only', '-Wall'] + lang + [header], capture_output=True, text=True)
+        assert res.returncode == 0, res.stderr
