@@ -59,10 +59,18 @@ size_t pcf_hip_launch_log_read(char* buf, size_t capacity);
  * 16-byte body, tail bytes) on HOST memory over `blocks` x 256 emulated threads -- a test hook that needs no GPU. */
 void pcf_hip_zero_host(void* p, size_t bytes, int blocks);
 /* Kernel family for the aggregate shapes the matrix-core kernels cover: 0 default, 1 LDS-tiled kernels (cross-check),
- * 2 tiled matrix-core kernels everywhere.  Process-wide; the environment (PCF_AGG_LDS=1 / PCF_AGG_TILED=1) only sets
+ * 2 tiled matrix-core kernels everywhere, 3 thread-per-edge backward of small unguided layers (see below).  Process-wide; the environment (PCF_AGG_LDS=1 / PCF_AGG_TILED=1) only sets
  * the initial value. */
 int pcf_hip_set_aggregate_engine(int engine);
 int pcf_hip_get_aggregate_engine(void);
+/* Engine 3 (opt-in, unmeasured): pconv_backward / pconv_linear*_backward of unguided layers with C_mid 4 or 16 and at most
+ * 64 channels per edge through a thread-per-edge kernel without LDS (the level-0 PointConv, layers.py:813-906).  Its
+ * per-edge body is __host__ __device__; pcf_hip_pconv_backward_edge_host runs it over every edge on HOST memory (test
+ * hook, no GPU; arguments as pcf_hip_pconv_backward plus `contrib` [B*Nout*K, C_in] and `atomic`: accumulate into a
+ * zeroed grad_x, or write per-edge contribution rows). */
+int pcf_hip_pconv_backward_edge_host(const float* grad_out, const float* x, const int64_t* idx, const float* w, const float* add,
+                                     float* grad_x, float* contrib, float* grad_w, float* grad_add, int B, int N, int Nout, int K,
+                                     int Ci, int Ca, int Cm, int atomic);
 /* Last pass of the fused edge-graph backward (pcf_hip_pcf_chain_backward / pcf_hip_weightnet_chain_backward): 1 = the
  * operands of its outer products are turned through LDS tiles (default: faster by 5 % at 1.28 M edges), 0 = they are
  * produced in registers in the transposed lane layout (no LDS traffic, more vector-memory instructions).  Process-wide;

@@ -917,6 +917,106 @@ __global__ __launch_bounds__(BLOCK) void csr_gather1_kernel(const float* __restr
     }
 }
 
+// ---- unguided backward with few channels: one THREAD per edge (engine 3, opt-in) --------------------------------
+// The level-0 PointConv of the 10cm / 5cm models (Ci 6, Ca 12, C_mid 16, K 16, 144k points) runs the generic LDS kernel at
+// 14 % of the HBM roof (716 us): three block-wide phases over a 22 KB tile for 18 channels of work.
+// Per edge the work is two short loops over the CT = Ci + Ca channels against the point's gout tile [CT][CM]:
+//     dT[c]   = sum_m gout[c][m] * w[e][m]      -> scatter / contribution row (c < Ci), grad_add (c >= Ci)
+//     gw[m]  += gout[c][m] * T[e][c]            T = gathered x row | appended features
+// so a lane can own an edge outright: its w row and gw accumulator stay in registers, the gout rows are 16-byte loads that
+// the 16 lanes of a point share (one cache line, broadcast), rows of w / add / grad_w / grad_add are lane-contiguous.  No
+// LDS, no barriers, no cross-lane traffic -- which also makes the body plain C++: agg_bwd_edge_item is __host__ __device__
+// and pcf_hip_pconv_backward_edge_host runs it on host memory, so the arithmetic is checked against the oracle on a CPU
+// (tests/test_abi_cpu.py).  Same fmaf order as agg_bwd_kernel: results are bit-identical to it (float atomics aside).
+// Not measured yet (written in a round without GPU access): selected only by pcf_hip_set_aggregate_engine(3).
+__host__ __device__ __forceinline__ void edge_atomic_add(float* p, float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicAdd(p, v);
+#else
+    *p += v;
+#endif
+}
+
+template <int CM, bool AL>
+__host__ __device__ __forceinline__ void edge_load_row(const float* p, float (&g)[CM]) {
+    if (AL) {
+#pragma unroll
+        for (int q = 0; q < CM / 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(p + 4 * q);
+            g[4 * q] = v.x; g[4 * q + 1] = v.y; g[4 * q + 2] = v.z; g[4 * q + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < CM; ++m) g[m] = p[m];
+    }
+}
+
+template <int CM, bool AL>
+__host__ __device__ __forceinline__ void agg_bwd_edge_item(const AggArgs& a, long long e, bool atomic_scatter) {
+    const int K = a.K, Ci = a.Ci, Ca = a.Ca, CT = Ci + Ca;
+    const long long n = e / K;
+    const int b = (int)(n / a.Nout);
+    const int64_t j = a.idx[e];
+    const long long row = (j >= 0 && j < a.N) ? (long long)b * a.N + j : -1;
+    float wv[CM], gw[CM], g[CM];
+    edge_load_row<CM, AL>(a.w + (size_t)e * CM, wv);
+#pragma unroll
+    for (int m = 0; m < CM; ++m) gw[m] = 0.f;
+    const float* go = a.gout + (size_t)n * CT * CM;
+    for (int c = 0; c < Ci; ++c) {                                   // gathered channels
+        const float t = row >= 0 ? a.x[(size_t)row * Ci + c] : 0.f;
+        edge_load_row<CM, AL>(go + (size_t)c * CM, g);
+        float dT = 0.f;
+#pragma unroll
+        for (int m = 0; m < CM; ++m) { dT = fmaf(g[m], wv[m], dT); gw[m] = fmaf(t, g[m], gw[m]); }
+        if (atomic_scatter) { if (row >= 0) edge_atomic_add(a.gx + (size_t)row * Ci + c, dT); }
+        else a.contrib[(size_t)e * Ci + c] = dT;
+    }
+    const float* ar = a.add + (size_t)e * Ca;                        // appended channels (never dereferenced when Ca = 0)
+    float* gar = a.gadd + (size_t)e * Ca;
+    int ca = 0;
+    if (AL && (Ca & 3) == 0) {
+        for (; ca < Ca; ca += 4) {
+            const float4 t4 = *reinterpret_cast<const float4*>(ar + ca);
+            const float tt[4] = {t4.x, t4.y, t4.z, t4.w};
+            float d[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                edge_load_row<CM, AL>(go + (size_t)(Ci + ca + u) * CM, g);
+                float dT = 0.f;
+#pragma unroll
+                for (int m = 0; m < CM; ++m) { dT = fmaf(g[m], wv[m], dT); gw[m] = fmaf(tt[u], g[m], gw[m]); }
+                d[u] = dT;
+            }
+            *reinterpret_cast<float4*>(gar + ca) = make_float4(d[0], d[1], d[2], d[3]);
+        }
+    }
+    for (; ca < Ca; ++ca) {
+        const float t = ar[ca];
+        edge_load_row<CM, AL>(go + (size_t)(Ci + ca) * CM, g);
+        float dT = 0.f;
+#pragma unroll
+        for (int m = 0; m < CM; ++m) { dT = fmaf(g[m], wv[m], dT); gw[m] = fmaf(t, g[m], gw[m]); }
+        gar[ca] = dT;
+    }
+    float* gwr = a.gw + (size_t)e * CM;
+    if (AL) {
+#pragma unroll
+        for (int q = 0; q < CM / 4; ++q)
+            *reinterpret_cast<float4*>(gwr + 4 * q) = make_float4(gw[4 * q], gw[4 * q + 1], gw[4 * q + 2], gw[4 * q + 3]);
+    } else {
+#pragma unroll
+        for (int m = 0; m < CM; ++m) gwr[m] = gw[m];
+    }
+}
+
+template <int CM, bool AL, bool ATOMIC>
+__global__ __launch_bounds__(BLOCK) void agg_bwd_edge_kernel(const AggArgs a) {
+    const long long E = (long long)a.total * a.K;
+    for (long long e = (long long)blockIdx.x * BLOCK + threadIdx.x; e < E; e += (long long)gridDim.x * BLOCK)
+        agg_bwd_edge_item<CM, AL>(a, e, ATOMIC);
+}
+
 // ---- host side ----------------------------------------------------------------------------------
 static int pow2_ceil(int v) {
     int p = 1;
@@ -932,12 +1032,14 @@ struct Plan {
     bool mfma_shape;       // K = 16, H = 8, guided, Ca = 0, Ci % 16 == 0, Cm in {4, 16}, 16-byte rows: the matrix-core kernels
     bool pconv_mfma_shape; // K = 16, unguided, Ci % 16 == 0, Ca % 16 == 0, Ci + Ca >= 16, Cm in {4, 16}, 16-byte rows
     int cm_t;   // template Cm (0 = run-time)
+    bool al;    // every pointer of the call is 16-byte aligned
 };
 
 static int make_plan(Plan& pl, bool backward, bool guided, int total, int K, int Ci, int Ca, int Cm, int H,
                      bool ptrs_aligned) {
     const int CT = Ci + Ca;
     pl.vrow = ptrs_aligned && (Ci % 4 == 0) && (Ca % 4 == 0);
+    pl.al = ptrs_aligned;
     const bool cm_vec = (Cm % 4 == 0);
     pl.cm_t = 0;
     if (Cm == 1) pl.cm_t = 1;
@@ -1018,6 +1120,7 @@ static int agg_engine() {
 }
 static bool agg_lds_only() { return agg_engine() == 1; }
 static bool agg_tiled_only() { return agg_engine() == 2; }
+static bool agg_edge_engine() { return agg_engine() == 3; }
 
 static int launch_fwd(const AggArgs& a, const Plan& pl, hipStream_t s) {
 #define PCF_FWD(CMV)                                                                   \
@@ -1053,8 +1156,27 @@ static int launch_fwd(const AggArgs& a, const Plan& pl, hipStream_t s) {
 #undef PCF_FWD
 }
 
+// thread-per-edge backward (engine 3): unguided, C_mid 4 or 16, at most 64 channels per edge
+static bool edge_covers(const AggArgs& a) { return !a.guid && (a.Cm == 16 || a.Cm == 4) && a.Ci + a.Ca <= 64 && a.Ci + a.Ca >= 1; }
+
+template <bool ATOMIC>
+static int launch_bwd_edge(const AggArgs& a, const Plan& pl, hipStream_t s) {
+    const long long E = (long long)a.total * a.K;
+    const int grid = (int)std::max<long long>(1, std::min<long long>((E + BLOCK - 1) / BLOCK, 256 * 64));
+    const dim3 gd(grid), bd(BLOCK);
+    if (a.Cm == 16) {
+        if (pl.al) hipLaunchKernelGGL((agg_bwd_edge_kernel<16, true, ATOMIC>), gd, bd, 0, s, a);
+        else hipLaunchKernelGGL((agg_bwd_edge_kernel<16, false, ATOMIC>), gd, bd, 0, s, a);
+    } else {
+        if (pl.al) hipLaunchKernelGGL((agg_bwd_edge_kernel<4, true, ATOMIC>), gd, bd, 0, s, a);
+        else hipLaunchKernelGGL((agg_bwd_edge_kernel<4, false, ATOMIC>), gd, bd, 0, s, a);
+    }
+    return check_launch(a.Cm == 16 ? "agg_bwd_edge_kernel<16>" : "agg_bwd_edge_kernel<4>");
+}
+
 template <bool ATOMIC>
 static int launch_bwd_mode(const AggArgs& a, const Plan& pl, hipStream_t s) {
+    if (agg_edge_engine() && edge_covers(a)) return launch_bwd_edge<ATOMIC>(a, pl, s);
 #define PCF_BWD(CMV)                                                                            \
     return pl.vrow ? launch(agg_bwd_kernel<CMV, true, ATOMIC>, a, pl, s, "agg_bwd_kernel<" #CMV ",true>")  \
                    : launch(agg_bwd_kernel<CMV, false, ATOMIC>, a, pl, s, "agg_bwd_kernel<" #CMV ",false>")
@@ -1264,11 +1386,34 @@ int pcf_hip_pcf_backward_csr(const float* grad_out, const float* x, const int32_
 }
 
 int pcf_hip_set_aggregate_engine(int engine) {
-    if (engine < 0 || engine > 2) return pcf::fail(PCF_E_BADARG, "set_aggregate_engine: 0 (default), 1 (LDS) or 2 (tiled), got %d", engine);
+    if (engine < 0 || engine > 3)
+        return pcf::fail(PCF_E_BADARG, "set_aggregate_engine: 0 (default), 1 (LDS), 2 (tiled) or 3 (thread-per-edge unguided backward), got %d", engine);
     pcf::g_agg_engine.store(engine, std::memory_order_relaxed);
     return pcf::ok();
 }
 
 int pcf_hip_get_aggregate_engine(void) { return pcf::agg_engine(); }
+
+// Host emulation of agg_bwd_edge_kernel: the same __host__ __device__ item function over every edge, on HOST memory
+// (test hook, no GPU).  grad_x accumulates (the caller zeroes it) when `atomic` != 0, else per-edge rows go to `contrib`.
+int pcf_hip_pconv_backward_edge_host(const float* grad_out, const float* x, const int64_t* idx, const float* w, const float* add,
+                                     float* grad_x, float* contrib, float* grad_w, float* grad_add, int B, int N, int Nout, int K,
+                                     int Ci, int Ca, int Cm, int atomic) {
+    using namespace pcf;
+    PCF_REQUIRE(Cm == 16 || Cm == 4, "pconv_backward_edge_host: C_mid must be 4 or 16 (got %d)", Cm);
+    PCF_REQUIRE(B >= 0 && N >= 0 && Nout >= 0 && K >= 1 && Ci >= 0 && Ca >= 0 && Ci + Ca >= 1 && Ci + Ca <= 64, "pconv_backward_edge_host: bad sizes");
+    PCF_REQUIRE(grad_out && idx && w && grad_w && (Ci == 0 || (x && (atomic ? grad_x != nullptr : contrib != nullptr))) && (Ca == 0 || (add && grad_add)),
+                "pconv_backward_edge_host: null pointer");
+    AggArgs a{};
+    a.x = x; a.idx = idx; a.w = w; a.add = add; a.gout = grad_out; a.gx = grad_x; a.contrib = contrib; a.gw = grad_w; a.gadd = grad_add;
+    a.total = B * Nout; a.N = N; a.Nout = Nout; a.K = K; a.Ci = Ci; a.Ca = Ca; a.Cm = Cm; a.H = 1;
+    const bool al = aligned16(x) && aligned16(w) && aligned16(grad_out) && aligned16(grad_w) && (Ca == 0 || (aligned16(add) && aligned16(grad_add)));
+    const long long E = (long long)a.total * K;
+    for (long long e = 0; e < E; ++e) {
+        if (Cm == 16) { if (al) agg_bwd_edge_item<16, true>(a, e, atomic != 0); else agg_bwd_edge_item<16, false>(a, e, atomic != 0); }
+        else { if (al) agg_bwd_edge_item<4, true>(a, e, atomic != 0); else agg_bwd_edge_item<4, false>(a, e, atomic != 0); }
+    }
+    return ok();
+}
 
 }  // extern "C"

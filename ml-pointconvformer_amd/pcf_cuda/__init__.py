@@ -93,7 +93,7 @@ _get_engine = _sig('pcf_hip_get_aggregate_engine', [])
 
 _set_chain_bwd_engine = _sig('pcf_hip_set_chain_backward_engine', [_I])
 
-AGG_ENGINES = {'default': 0, 'lds': 1, 'tiled': 2}
+AGG_ENGINES = {'default': 0, 'lds': 1, 'tiled': 2, 'edge': 3}
 
 
 def set_chain_backward_engine(lds_transposes: bool):
@@ -138,7 +138,8 @@ def set_flin_split_k(mode: int):
 
 def set_aggregate_engine(name: str):
     """'default' | 'lds' | 'tiled': the kernel family behind pcf_forward/backward and pconv_* for the shapes the
-    matrix-core kernels cover (process-wide; the cross-checks of the test-suite toggle it)."""
+    matrix-core kernels cover (process-wide; the cross-checks of the test-suite toggle it).  'edge': additionally the
+    thread-per-edge backward for unguided layers with C_mid 4 / 16 and <= 64 channels per edge (opt-in, unmeasured)."""
     if _set_engine(AGG_ENGINES[name]) != 0:
         raise RuntimeError(_last_error().decode())
 

@@ -118,11 +118,63 @@ def run_tables_case(name, scenes, points, rounds, dev):
             'n_wrong': len(wrong)}
 
 
+def run_edge_engine_cases(dev):
+    """The opt-in thread-per-edge backward (pcf_hip_set_aggregate_engine(3), csrc/aggregate.hip:agg_bwd_edge_kernel; its
+    body is checked against the oracle on the CPU) against the default kernels on the GPU: pconv_backward (float atomics)
+    and pconv_linear_opt_backward (contribution rows + CSR reduce: deterministic, so bit-identical), at the level-0
+    PointConv shape of the 10cm / 5cm models and three more.  First hardware run of this kernel: in the child process."""
+    import pcf_cuda
+    out = []
+    for (N, Nout, K, Ci, Ca, Cm, Co) in ((20000, 20000, 16, 6, 12, 16, 64), (5000, 1300, 16, 16, 16, 4, 32), (3000, 3000, 8, 3, 0, 16, 32),
+                                         (777, 500, 16, 7, 5, 16, 24)):
+        g = torch.Generator().manual_seed(N + Ci)
+        x = torch.randn(1, N, Ci, generator=g).to(dev)
+        idx = torch.randint(0, N, (1, Nout, K), generator=g)
+        idx[0, ::7, 3] = -1                                                   # out-of-range entries: skipped on every path
+        idx = idx.to(dev)
+        w = torch.randn(1, Nout, K, Cm, generator=g).to(dev)
+        add = torch.randn(1, Nout, K, Ca, generator=g).to(dev)
+        gout = torch.randn(1, Nout, (Ci + Ca) * Cm, generator=g).to(dev)
+        lin_w = (torch.randn(Co, (Ci + Ca) * Cm, generator=g) / 16).to(dev)
+        lin_b = torch.zeros(Co, device=dev)
+        gout_lin = torch.randn(1, Nout, Co, generator=g).to(dev)
+        inv = pcf_cuda.compute_knn_inverse(idx, N)
+        res = {}
+        for engine in ('default', 'edge'):
+            pcf_cuda.set_aggregate_engine(engine)
+            pcf_cuda.launch_log(True)
+            a = pcf_cuda.pconv_backward(gout, x, idx, w, add)
+            _, pconv_out = pcf_cuda.pconv_linear_forward(x, idx, w, add, lin_w, lin_b)
+            b = pcf_cuda.pconv_linear_opt_backward(gout_lin, x, inv[0], inv[1], inv[2], idx, w, add, lin_w, pconv_out)
+            torch.cuda.synchronize()
+            res[engine] = ([t.cpu() for t in a], [t.cpu() for t in b], pcf_cuda.read_launch_log())
+            pcf_cuda.launch_log(False)
+        pcf_cuda.set_aggregate_engine('default')
+        (a0, b0, log0), (a1, b1, log1) = res['default'], res['edge']
+        scale = lambda t: float(t.abs().max()) + 1e-30
+        err = lambda p, q: (float((p - q).abs().max()) / scale(p)) if p.numel() else 0.0
+        rec = {'edge_case': [N, Nout, K, Ci, Ca, Cm], 'edge_kernel_ran': sum('agg_bwd_edge_kernel' in l for l in log1),
+               'edge_kernel_in_default': sum('agg_bwd_edge_kernel' in l for l in log0),
+               # the generic LDS kernel runs the same fmaf chains (bit-identical grad_w / grad_add / contribution rows);
+               # the matrix-core kernels of the default dispatch sum in another order
+               'default_is_generic_lds_kernel': all('mfma' not in l for l in log0 if 'bwd' in l and 'agg' in l or 'pconv_bwd' in l),
+               'atomic_err': [err(p, q) for p, q in zip(a0, a1)], 'csr_err': [err(p, q) for p, q in zip(b0, b1)],
+               'atomic_grad_w_equal': bool(torch.equal(a0[1], a1[1])), 'atomic_grad_add_equal': bool(torch.equal(a0[2], a1[2])),
+               'csr_equal': [bool(torch.equal(p, q)) for p, q in zip(b0, b1)]}
+        out.append(rec)
+        print(json.dumps(rec), flush=True)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--cases', default='small')
     args = ap.parse_args()
     dev = torch.device(os.environ.get('PCF_TEST_DEVICE', 'cuda:0'))          # tools/dry_env.py runs this on the CPU
+    if args.cases == 'edge':
+        run_edge_engine_cases(dev)
+        print(json.dumps({'done': True}), flush=True)
+        return
     small = [('configPCF_10cm_lite', 2, 3000), ('configPCF_10cm', 2, 3000), ('configPCF_5cm', 1, 6000),
              ('configPCF_2cm_PTF2', 2, 6000)]
     cases = [(n, s, p, 6, True) for n, s, p in small]

@@ -104,3 +104,79 @@ def test_public_header_is_plain_c():
             pytest.skip(f'no {cc} in this image')
         res = subprocess.run([cc, '-fsyntax-only', '-Wall'] + lang + [header], capture_output=True, text=True)
         assert res.returncode == 0, res.stderr
+
+
+@pytest.mark.parametrize('B,N,Nout,K,Ci,Ca,Cm', [(1, 300, 300, 16, 6, 12, 16), (2, 90, 41, 8, 3, 0, 16), (1, 64, 64, 16, 16, 16, 4),
+                                               (1, 50, 70, 5, 7, 5, 16), (1, 33, 33, 16, 1, 12, 4)])
+def test_thread_per_edge_backward_body_against_oracle(B, N, Nout, K, Ci, Ca, Cm):
+    """csrc/aggregate.hip:agg_bwd_edge_item -- the per-edge body of the opt-in thread-per-edge backward (engine 3) -- is
+    __host__ __device__: pcf_hip_pconv_backward_edge_host runs it over every edge on host memory.  Against
+    oracle.pcf_oracle.pconv_backward (autograd adjoint of layers.py:890-897): grad_w, grad_add, and grad_x both as an
+    accumulation and as per-edge contribution rows summed over the edges; aligned and misaligned buffers (both load paths)."""
+    import numpy as np
+    import pcf_cuda
+    from oracle import pcf_oracle as O
+    lib = ctypes.CDLL(pcf_cuda.library_path())
+    fn = lib.pcf_hip_pconv_backward_edge_host
+    fn.argtypes = [ctypes.c_void_p] * 9 + [ctypes.c_int] * 8
+    fn.restype = ctypes.c_int
+    g = torch.Generator().manual_seed(B * 1000 + N + Ci)
+    x = torch.randn(B, N, Ci, generator=g)
+    idx = torch.randint(0, N, (B, Nout, K), generator=g)
+    w = torch.randn(B, Nout, K, Cm, generator=g)
+    add = torch.randn(B, Nout, K, Ca, generator=g)
+    gout = torch.randn(B, Nout, (Ci + Ca) * Cm, generator=g)
+    want_x, want_w, want_add = O.pconv_backward(gout, x, idx, w, add)
+
+    def buf(t, shift):          # a copy of t at a 16-byte boundary (+ shift floats): aligned and misaligned runs
+        store = np.zeros(t.numel() + 8, np.float32)
+        off = (-store.ctypes.data // 4) % 4 + shift
+        view = store[off:off + t.numel()]
+        view[:] = t.reshape(-1).numpy()
+        return store, view
+
+    ptr = lambda v: ctypes.c_void_p(v.ctypes.data) if v.size else None
+    for shift in (0, 1):
+        keep = [buf(t, shift) for t in (gout, x, w, add)]
+        (_, vg), (_, vx), (_, vw), (_, va) = keep
+        idx_np = np.ascontiguousarray(idx.numpy())
+        for atomic in (1, 0):
+            gx = np.zeros(B * N * Ci, np.float32)
+            contrib = np.zeros(B * Nout * K * Ci, np.float32)
+            sgw, gw = buf(torch.zeros(B * Nout * K * Cm), shift)
+            sga, ga = buf(torch.zeros(B * Nout * K * Ca), shift)
+            rc = fn(ptr(vg), ptr(vx), ctypes.c_void_p(idx_np.ctypes.data), ptr(vw), ptr(va), ptr(gx), ptr(contrib), ptr(gw), ptr(ga),
+                    B, N, Nout, K, Ci, Ca, Cm, atomic)
+            assert rc == 0
+            torch.testing.assert_close(torch.from_numpy(gw.copy()).reshape(want_w.shape), want_w, rtol=1e-5, atol=1e-5)
+            if Ca:
+                torch.testing.assert_close(torch.from_numpy(ga.copy()).reshape(want_add.shape), want_add, rtol=1e-5, atol=1e-5)
+            if Ci:
+                if atomic:
+                    got = torch.from_numpy(gx).reshape(B, N, Ci)
+                else:
+                    got = torch.zeros(B, N, Ci)
+                    rows = torch.from_numpy(contrib).reshape(B, Nout * K, Ci)
+                    for b in range(B):
+                        got[b].index_add_(0, idx[b].reshape(-1), rows[b])
+                torch.testing.assert_close(got, want_x, rtol=1e-4, atol=1e-4)
+    # out-of-range neighbour indices contribute nothing and receive nothing (the library's rule for every aggregate)
+    if Ci:
+        bad = idx.clone()
+        bad[:, ::3, 0] = -1
+        bad[:, 1::3, 1] = N + 5
+        valid = (bad >= 0) & (bad < N)
+        safe = torch.where(valid, bad, torch.zeros_like(bad))
+        xs = torch.cat([x, torch.zeros(B, 1, Ci)], 1)                       # row N = zeros for the invalid slots
+        idx_o = torch.where(valid, safe, torch.full_like(bad, N))
+        want_x2, want_w2, want_add2 = O.pconv_backward(gout, xs, idx_o, w, add)
+        gx = np.zeros(B * N * Ci, np.float32)
+        gw = np.zeros(B * Nout * K * Cm, np.float32)
+        ga = np.zeros(max(B * Nout * K * Ca, 1), np.float32)
+        bad_np = np.ascontiguousarray(bad.numpy())
+        arr = lambda t: np.ascontiguousarray(t.reshape(-1).numpy())
+        vg, vx, vw, va = arr(gout), arr(x), arr(w), arr(add)
+        assert fn(ptr(vg), ptr(vx), ctypes.c_void_p(bad_np.ctypes.data), ptr(vw), ptr(va), ptr(gx), None, ptr(gw), ptr(ga) if Ca else None,
+                  B, N, Nout, K, Ci, Ca, Cm, 1) == 0
+        torch.testing.assert_close(torch.from_numpy(gx).reshape(B, N, Ci), want_x2[:, :N], rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(torch.from_numpy(gw).reshape(want_w2.shape), want_w2, rtol=1e-5, atol=1e-5)

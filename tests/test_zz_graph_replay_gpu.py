@@ -34,6 +34,8 @@ def _run_child(cases, timeout):
     tail = '\n'.join(res.stdout.splitlines()[-6:]) + '\n--- stderr ---\n' + res.stderr[-1500:]
     assert res.returncode == 0, f'child exited with {res.returncode} (negative / 134 = aborted, e.g. by a GPU fault):\n{tail}'
     assert recs and recs[-1].get('done'), tail
+    if cases == 'edge':
+        return [r for r in recs if 'edge_case' in r]
     tables = [r for r in recs if 'tables_case' in r]
     assert len(tables) == 2, tail
     for t in tables:          # neighbour tables and CSR of every replay bit-identical to eagerly built ones
@@ -194,3 +196,20 @@ def test_voxelize_float64_coordinates(device):
     assert np.array_equal(key[idx], key[ref_idx])
     idx32 = U.voxelize(coord.astype(np.float32), vs, mode='deterministic').cpu().numpy()
     assert np.array_equal(idx32, V.voxelize(coord.astype(np.float32), vs)[0]) and not np.array_equal(idx32, idx)
+
+
+@pytest.mark.timeout(900)
+def test_thread_per_edge_backward_engine_against_default_kernels():
+    """pcf_hip_set_aggregate_engine(3): the thread-per-edge backward of small unguided layers (level-0 PointConv of the
+    10cm / 5cm models) -- opt-in and unmeasured, its arithmetic checked against the oracle on the CPU
+    (tests/test_abi_cpu.py) -- against the default kernels on the GPU, in a child process (first hardware run): the kernel
+    is the one that ran, grad_w / grad_add and the whole CSR path are bit-identical (same fmaf chains), the atomics path
+    agrees to rounding."""
+    recs = _run_child('edge', 800)
+    assert len(recs) == 4
+    for r in recs:
+        assert r['edge_kernel_ran'] == 2 and r['edge_kernel_in_default'] == 0, r
+        assert max(r['atomic_err']) < 1e-5 and max(r['csr_err']) < 1e-5, r
+        if r['default_is_generic_lds_kernel']:
+            assert r['atomic_grad_w_equal'] and r['atomic_grad_add_equal'] and all(r['csr_equal']), r
+    assert sum(r['default_is_generic_lds_kernel'] for r in recs) >= 3
