@@ -27,7 +27,7 @@ for p in (ROOT, os.path.join(ROOT, 'ml-pointconvformer_amd')):
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-CALLS = {'n': 0, 'by_name': {}}
+CALLS = {'n': 0, 'by_name': {}, 'trace': None}
 
 
 def install_stubs():
@@ -46,6 +46,9 @@ def install_stubs():
     def no_launch(fn, *args):
         CALLS['n'] += 1
         CALLS['by_name'][fn.__name__] = CALLS['by_name'].get(fn.__name__, 0) + 1
+        if CALLS['trace'] is not None:          # entry point + its integer arguments (sizes, flags); pointers and floats left out
+            ints = [a for a in args if isinstance(a, int) and not isinstance(a, bool) and abs(a) < (1 << 31)]
+            CALLS['trace'].append(fn.__name__.replace('pcf_hip_', '') + ' ' + ' '.join(str(a) for a in ints))
 
     class NoGuard:
         def __init__(self, dev):
@@ -107,6 +110,7 @@ def main():
     ap.add_argument('--top', type=int, default=35)
     ap.add_argument('--no-opt', action='store_true', help='forward + backward only (the CPU optimizer is not what the GPU path runs)')
     ap.add_argument('--sort', default='tottime')
+    ap.add_argument('--trace', default=None, help='write the C-ABI calls of ONE iteration (entry point + integer arguments) to this file')
     ap.add_argument('--dp', action='store_true', help="the iteration as pcf_train.DataParallelStep's eager halves (one process)")
     args = ap.parse_args()
     torch.set_num_threads(1)
@@ -135,6 +139,13 @@ def main():
         return pcf_train.training_iteration(net, opt, crit, cfg, batch)
 
     step()                                           # first call: lazy module state
+    if args.trace:
+        CALLS['trace'] = []
+        step()
+        with open(args.trace, 'w') as f:
+            f.write('\n'.join(CALLS['trace']) + '\n')
+        print(f'{len(CALLS["trace"])} calls written to {args.trace}', flush=True)
+        CALLS['trace'] = None
     CALLS['n'], CALLS['by_name'] = 0, {}
     prof = cProfile.Profile() if args.profile else None
     t0 = time.perf_counter()
